@@ -1,0 +1,418 @@
+"""CPU oracle for the DRAM DC3D hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain torch-CPU / numpy restatement of the algorithm in the
+reference's ``dram/parts.py`` and ``dram/models.py`` (class ``DC3D``).  It is
+imported only by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never by the product path
+(``bodyct-dram_amd/``), which fails loudly when the HIP library is missing.
+
+Parity pin: every function here is checked against golden vectors produced by
+importing the reference itself on CPU (``oracle/make_golden.py`` ->
+``tests/golden/*.npz``, checked by ``tests/test_oracle_golden.py``).
+
+Everything is fp32, NCDHW.  Parameters travel in a flat dict keyed by the
+reference's state-dict names (``ds_modules.0.conv_blocks.0.0.weight`` ...), so
+that a reference checkpoint, the oracle and the HIP modules are interchangeable.
+
+Two layers of restatement:
+  * ``np_*``  - slow, loop/numpy definitions of each op from first principles
+                (used on tiny shapes to pin the op semantics themselves);
+  * the rest  - torch-CPU functional code with the reference's wiring, used at
+                sizes the tests / the CPU baseline need.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+EPS = 1e-5          # torch default for BatchNorm3d / GroupNorm (reference parts.py:19-31 passes none)
+BN_MOMENTUM = 0.1   # torch default
+
+# The shipped benchmark model: reference dram/exp_settings/st_dram_ref.py:54-71.
+ST_DRAM_REF_MODEL = {
+    "n_layers": 3,
+    "in_ch_list": [1, 64, 128, 256, 768, 384, 192],
+    "base_ch_list": [32, 64, 128, 256, 256, 128, 64],
+    "end_ch_list": [64, 128, 256, 512, 256, 128, 64],
+    "kernel_sizes": [(3, 3)] * 7,
+    "stacking": 3,
+    "padding_list": [(1, 1)] * 7,
+    "checkpoint_layers": [0, 1, 0, 1, 0, 1, 0],
+    "dropout": 0.0,
+    "upsample_ksize": (3, 3, 3),
+    "upsample_sf": (2, 2, 2),
+    "out_ch": 1,
+}
+
+
+# --------------------------------------------------------------------------
+# first-principles numpy definitions (tiny shapes only)
+# --------------------------------------------------------------------------
+def np_conv3d(x, w, bias=None, pad=1):
+    """y[n,o,z,y,x] = sum_{c,dz,dy,dx} w[o,c,dz,dy,dx] * xpad[n,c,z+dz,y+dy,x+dx]
+    (cross-correlation, stride 1, zero padding) -- what nn.Conv3d in
+    reference parts.py:177 computes."""
+    N, C, D, H, W = x.shape
+    O, _, k, _, _ = w.shape
+    xp = np.zeros((N, C, D + 2 * pad, H + 2 * pad, W + 2 * pad), dtype=np.float64)
+    xp[:, :, pad:pad + D, pad:pad + H, pad:pad + W] = x
+    Do, Ho, Wo = D + 2 * pad - k + 1, H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    y = np.zeros((N, O, Do, Ho, Wo), dtype=np.float64)
+    for dz in range(k):
+        for dy in range(k):
+            for dx in range(k):
+                patch = xp[:, :, dz:dz + Do, dy:dy + Ho, dx:dx + Wo]
+                y += np.einsum("nczyx,oc->nozyx", patch, w[:, :, dz, dy, dx].astype(np.float64))
+    if bias is not None:
+        y += bias.reshape(1, -1, 1, 1, 1)
+    return y.astype(np.float32)
+
+
+def np_maxpool2(x):
+    """2x2x2 / stride 2 / no padding max pool with floor sizes (parts.py:191).
+    Returns (out, idx) with idx in 0..7 = first maximum in (z,y,x) scan order
+    (the element ATen's CPU kernel routes the gradient to)."""
+    N, C, D, H, W = x.shape
+    Do, Ho, Wo = D // 2, H // 2, W // 2
+    out = np.empty((N, C, Do, Ho, Wo), dtype=x.dtype)
+    idx = np.empty((N, C, Do, Ho, Wo), dtype=np.uint8)
+    for z in range(Do):
+        for y in range(Ho):
+            for xx in range(Wo):
+                win = x[:, :, 2 * z:2 * z + 2, 2 * y:2 * y + 2, 2 * xx:2 * xx + 2].reshape(N, C, 8)
+                out[:, :, z, y, xx] = win.max(-1)
+                idx[:, :, z, y, xx] = win.argmax(-1)  # numpy argmax = first occurrence
+    return out, idx
+
+
+def _ac_axis(n_in, n_out):
+    """align_corners=True source coordinates for one axis, computed like ATen
+    (area_pixel_compute_scale / compute_source_index): scale=(in-1)/(out-1) in
+    fp32, src = scale*dst, i0=int(src), lam1=src-i0, i1=i0+(i0<in-1)."""
+    scale = np.float32(0.0) if n_out <= 1 else np.float32(n_in - 1) / np.float32(n_out - 1)
+    dst = np.arange(n_out, dtype=np.float32)
+    src = scale * dst
+    i0 = src.astype(np.int64)
+    i0 = np.minimum(i0, n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = (src - i0.astype(np.float32)).astype(np.float32)
+    l0 = (np.float32(1.0) - l1).astype(np.float32)
+    return i0, i1, l0, l1
+
+
+def np_trilinear_ac(x, size):
+    """nn.Upsample(mode='trilinear', align_corners=True) to `size`
+    (parts.py:149, models.py:146)."""
+    N, C, D, H, W = x.shape
+    Do, Ho, Wo = size
+    z0, z1, a0, a1 = _ac_axis(D, Do)
+    y0, y1, b0, b1 = _ac_axis(H, Ho)
+    x0, x1, c0, c1 = _ac_axis(W, Wo)
+    xf = x.astype(np.float32)
+    out = np.zeros((N, C, Do, Ho, Wo), dtype=np.float32)
+    for (zi, za) in ((z0, a0), (z1, a1)):
+        for (yi, yb) in ((y0, b0), (y1, b1)):
+            for (xi, xc) in ((x0, c0), (x1, c1)):
+                wgt = (za[:, None, None] * yb[None, :, None] * xc[None, None, :]).astype(np.float32)
+                out += wgt * xf[:, :, zi[:, None, None], yi[None, :, None], xi[None, None, :]]
+    return out
+
+
+def np_batchnorm_train(x, gamma, beta, eps=EPS):
+    """Training-mode BatchNorm3d: per-channel mean / biased variance over
+    (N,D,H,W) (parts.py:19).  Returns y, mean, biased var."""
+    xd = x.astype(np.float64)
+    mean = xd.mean(axis=(0, 2, 3, 4))
+    var = xd.var(axis=(0, 2, 3, 4))
+    sh = (1, -1, 1, 1, 1)
+    y = (xd - mean.reshape(sh)) / np.sqrt(var.reshape(sh) + eps)
+    if gamma is not None:
+        y = y * gamma.reshape(sh) + beta.reshape(sh)
+    return y.astype(np.float32), mean.astype(np.float32), var.astype(np.float32)
+
+
+def np_groupnorm(x, groups, gamma, beta, eps=EPS):
+    """GroupNorm(groups, C): per-(sample, group) mean / biased variance over
+    (C/G, D, H, W) (parts.py:26-31; 'ln' = 1 group, 'in' = C groups)."""
+    N, C = x.shape[:2]
+    xd = x.astype(np.float64).reshape(N, groups, -1)
+    mean = xd.mean(-1, keepdims=True)
+    var = xd.var(-1, keepdims=True)
+    y = ((xd - mean) / np.sqrt(var + eps)).reshape(x.shape)
+    if gamma is not None:
+        sh = (1, -1, 1, 1, 1)
+        y = y * gamma.reshape(sh) + beta.reshape(sh)
+    return y.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# op-level torch-CPU restatement
+# --------------------------------------------------------------------------
+def conv3d(x, w, bias=None, pad=1):
+    """nn.Conv3d(stride=1) of parts.py:177 / models.py:109."""
+    return F.conv3d(x, w, bias, stride=1, padding=pad)
+
+
+def crop_offsets(small, big):
+    """Start offsets of the centre crop in crop_concat_5d: ceil((b-a)/2) per
+    spatial axis (parts.py:42-44)."""
+    return tuple(int(math.ceil((b - a) / 2)) for a, b in zip(small, big))
+
+
+def crop_concat_5d(t1, t2):
+    """cat([t1, centre_crop(t2 -> t1 spatial)], dim=1) (parts.py:37-46):
+    t1 (the upsampled tensor) comes FIRST."""
+    assert t1.dim() == t2.dim() == 5
+    assert t1.shape[-1] <= t2.shape[-1]
+    oz, oy, ox = crop_offsets(t1.shape[2:], t2.shape[2:])
+    d, h, w = t1.shape[2:]
+    return torch.cat([t1, t2[:, :, oz:oz + d, oy:oy + h, ox:ox + w]], dim=1)
+
+
+def upsample_trilinear_ac(x, scale_factor=None, size=None):
+    """nn.Upsample(mode='trilinear', align_corners=True) (parts.py:149,
+    models.py:146)."""
+    return F.interpolate(x, size=size, scale_factor=scale_factor, mode="trilinear", align_corners=True)
+
+
+def max_pool3d_2(x):
+    """nn.MaxPool3d(2, 2, 0) (parts.py:191)."""
+    return F.max_pool3d(x, kernel_size=2, stride=2, padding=0)
+
+
+def pooling_dense_features(dense_outs, lungs, pooling_method="avg"):
+    """models.py:37-49."""
+    B, C = dense_outs.shape[0], dense_outs.shape[1]
+    if pooling_method == "global_avg":
+        return F.adaptive_avg_pool3d(dense_outs, 1).view(B, C)
+    if pooling_method == "global_max":
+        return F.adaptive_max_pool3d(dense_outs, 1).view(B, C)
+    le = lungs.expand_as(dense_outs)
+    return (dense_outs * le).view(B, C, -1).sum(dim=-1) / le.view(B, C, -1).sum(dim=-1)
+
+
+def _norm(method, prefix, params, buffers, x, training):
+    """normal_wrapper (parts.py:17-35) applied functionally.
+
+    `buffers` (running_mean / running_var / num_batches_tracked) is updated in
+    place in training mode exactly like nn.BatchNorm3d (momentum 0.1, unbiased
+    variance into running_var)."""
+    if method in ("bn", "sbn"):
+        rm, rv = buffers[prefix + ".running_mean"], buffers[prefix + ".running_var"]
+        if training:
+            buffers[prefix + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, rm, rv, params[prefix + ".weight"], params[prefix + ".bias"],
+                            training, BN_MOMENTUM, EPS)
+    if method == "bnt":
+        return F.batch_norm(x, None, None, params[prefix + ".weight"], params[prefix + ".bias"],
+                            True, BN_MOMENTUM, EPS)
+    if method == "bntna":
+        return F.batch_norm(x, None, None, None, None, True, BN_MOMENTUM, EPS)
+    if method == "ln":
+        return F.group_norm(x, 1, params[prefix + ".weight"], params[prefix + ".bias"], EPS)
+    if method == "lnna":
+        return F.group_norm(x, 1, None, None, EPS)
+    if method == "in":
+        return F.group_norm(x, x.shape[1], params[prefix + ".weight"], params[prefix + ".bias"], EPS)
+    return x  # Identity (parts.py:35)
+
+
+def conv_norm_act_stack(prefix, n_convs, params, buffers, x, norm_method, training, pads):
+    """The `conv_blocks` Sequential of all three block types
+    (parts.py:102-110, 138-146, 183-190): [Conv3d -> norm -> ReLU] * n."""
+    for j in range(n_convs):
+        p = f"{prefix}.conv_blocks.{j}"
+        x = conv3d(x, params[p + ".0.weight"], params.get(p + ".0.bias"), pads[j])
+        x = _norm(norm_method, p + ".1", params, buffers, x, training)
+        x = F.relu(x)
+    return x
+
+
+def _pads(cfg, n):
+    p = cfg["padding_list"][n]
+    return list(p) if isinstance(p, (tuple, list)) else [p, p]
+
+
+def dc3d_forward(cfg, params, buffers, x, training=False, norm_method="bn", use_checkpoint=True):
+    """DC3D.forward (models.py:120-147) for `cfg` (a MODEL dict without
+    'method').  Returns dense_outs [N, out_ch, D, H, W] (the reference returns
+    this same tensor twice).
+
+    With `use_checkpoint` the blocks flagged in cfg['checkpoint_layers'] go
+    through torch.utils.checkpoint like the reference does, which re-runs their
+    forward during backward and therefore updates their BatchNorm running
+    statistics twice per training step."""
+    L = cfg["n_layers"]
+    ck = cfg["checkpoint_layers"]
+    grad_mode = torch.is_grad_enabled()
+
+    def run(fn, flag, *args):
+        if use_checkpoint and flag > 0 and grad_mode:
+            return checkpoint(fn, *args, use_reentrant=True)
+        return fn(*args)
+
+    feats = []
+    cur = x
+    for n in range(L):
+        def ds(inp, n=n):
+            y = conv_norm_act_stack(f"ds_modules.{n}", 2, params, buffers, inp, norm_method, training, _pads(cfg, n))
+            return y, max_pool3d_2(y)
+        if ck[n] > 0 and n == 0:
+            # models.py:125 passes a dummy requires-grad tensor so the reentrant
+            # checkpoint of the first block still records a graph.
+            dummy = torch.ones(1, requires_grad=True)
+            y, cur = run(lambda inp, _d: ds(inp), ck[n], cur, dummy)
+        else:
+            y, cur = run(ds, ck[n], cur)
+        feats.append(y)
+
+    def bg(inp):
+        return conv_norm_act_stack("bg", 2, params, buffers, inp, norm_method, training, _pads(cfg, L))
+    cur = run(bg, ck[L], cur)
+
+    if (L + 1) < len(cfg["in_ch_list"]):
+        for idx, skip in enumerate(reversed(feats)):
+            if cfg.get("stacking", 0) == idx:
+                break
+
+            def us(inp, cat, idx=idx):
+                up = upsample_trilinear_ac(inp, scale_factor=tuple(cfg["upsample_sf"])
+                                           if isinstance(cfg["upsample_sf"], (tuple, list)) else cfg["upsample_sf"])
+                z = crop_concat_5d(up, cat)
+                return conv_norm_act_stack(f"us_modules.{idx}", 2, params, buffers, z, norm_method, training,
+                                           _pads(cfg, L + 1 + idx))
+            # NB models.py:140 indexes the flag with n_layers + idx (not +1).
+            cur = run(us, ck[L + idx], cur, skip)
+
+    dense = conv3d(cur, params["top_layer.weight"], params["top_layer.bias"], 0)
+    dense = upsample_trilinear_ac(dense, size=tuple(x.shape[-3:]))
+    return dense
+
+
+def init_params(cfg, norm_method="bn", seed=0):
+    """Random-init parameters with the reference's HeNorm(mode='fan_in')
+    statistics (models.py:17-35): conv weight ~ kaiming_normal(fan_in), conv
+    bias 0.01, norm weight 1 / bias 0.  (Not the same random stream as
+    constructing the reference modules -- use a golden state dict for that.)"""
+    g = torch.Generator().manual_seed(seed)
+    L = cfg["n_layers"]
+    params, buffers = {}, {}
+    conv_bias = norm_method is None
+
+    def add_stack(prefix, cins, couts):
+        for j, (ci, co) in enumerate(zip(cins, couts)):
+            std = math.sqrt(2.0 / (ci * 27))
+            params[f"{prefix}.conv_blocks.{j}.0.weight"] = torch.randn(co, ci, 3, 3, 3, generator=g) * std
+            if conv_bias:
+                params[f"{prefix}.conv_blocks.{j}.0.bias"] = torch.full((co,), 0.01)
+            if norm_method in ("bn", "sbn", "bnt", "ln", "in"):
+                params[f"{prefix}.conv_blocks.{j}.1.weight"] = torch.ones(co)
+                params[f"{prefix}.conv_blocks.{j}.1.bias"] = torch.zeros(co)
+            if norm_method in ("bn", "sbn"):
+                buffers[f"{prefix}.conv_blocks.{j}.1.running_mean"] = torch.zeros(co)
+                buffers[f"{prefix}.conv_blocks.{j}.1.running_var"] = torch.ones(co)
+                buffers[f"{prefix}.conv_blocks.{j}.1.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    names = [f"ds_modules.{n}" for n in range(L)] + ["bg"] + [f"us_modules.{n}" for n in range(L)]
+    for n, name in enumerate(names):
+        if n >= len(cfg["in_ch_list"]):
+            break
+        add_stack(name, [cfg["in_ch_list"][n], cfg["base_ch_list"][n]],
+                  [cfg["base_ch_list"][n], cfg["end_ch_list"][n]])
+    cin_top = cfg["end_ch_list"][L + cfg.get("stacking", 0)]
+    params["top_layer.weight"] = torch.randn(cfg["out_ch"], cin_top, 1, 1, 1, generator=g) * math.sqrt(2.0 / cin_top)
+    params["top_layer.bias"] = torch.full((cfg["out_ch"],), 0.01)
+    return params, buffers
+
+
+def split_state_dict(sd):
+    """Reference state dict -> (params, buffers) float32/long CPU tensors."""
+    params, buffers = {}, {}
+    for k, v in sd.items():
+        t = torch.as_tensor(v).clone()
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            buffers[k] = t
+        else:
+            params[k] = t
+    return params, buffers
+
+
+# --------------------------------------------------------------------------
+# loss restatement (reference dram/metrics.py)
+# --------------------------------------------------------------------------
+CTSS_RATIO_MAP = {0: (0.0, 0.001), 1: (0.001, 0.01), 2: (0.01, 0.05),
+                  3: (0.05, 0.35), 4: (0.35, 0.5), 5: (0.5, 1.00001)}   # metrics.py:76-83
+
+
+def get_labels(ctsses, lesion_ps, band_width):
+    """IntRegLoss.get_labels (metrics.py:122-138)."""
+    labels = []
+    for ctss, lesion_p in zip(ctsses, lesion_ps):
+        lp = float(lesion_p)
+        lb, ub = max(0.0, lp - band_width), min(1.0, lp + band_width)
+        c_lb, c_ub = CTSS_RATIO_MAP[int(float(ctss))]
+        band = (max(c_lb, lb), min(c_ub, ub))
+        if band[1] < band[0]:
+            if ub <= c_lb:
+                band = (lb, ub)
+            elif lb >= c_ub:
+                band = (c_lb, c_ub)
+            else:
+                raise RuntimeError("cannot reach here!")
+        labels.append(band)
+    return torch.tensor(labels, dtype=torch.float32)
+
+
+def reg_loss_with_probs(probs, lobes, lesions, ctsses, freq_map, band_width):
+    """IntRegLoss.compute_reg_loss_with_probs (metrics.py:158-177)."""
+    B = probs.shape[0]
+    ratio_ub = (lesions * lobes).view(B, 1, -1).sum(-1) / lobes.view(B, 1, -1).sum(-1)
+    m = (lobes > 0).to(probs.dtype)
+    pred_ratio = (probs * m).view(B, -1).sum(-1) / m.view(B, -1).sum(-1)   # == mean of probs[lobes>0] per sample
+    tgt = get_labels(ctsses, ratio_ub.view(-1), band_width).to(probs.device)
+    K = (0.5 * (tgt[:, 1] - tgt[:, 0])) ** 2
+    unh = (pred_ratio - (tgt[:, 1] + tgt[:, 0]) / 2.0) ** 2 - K
+    unw = torch.clamp(unh, min=0.0)
+    wf = torch.tensor([freq_map[int(float(c))] for c in ctsses], dtype=torch.float32, device=probs.device)
+    wf = torch.clamp(wf, 0.2, 0.8)
+    return (unw / wf).sum()
+
+
+def boot_bce(p, t, voi, smoothing=0.1, eps=1e-7):
+    """BootBinCrossEntropy.__call__ (metrics.py:17-51)."""
+    t = t.to(p.dtype)
+    tb = voi < 1e-7 if voi.dtype != torch.bool else ~voi
+    po, to = p[tb], t[tb]
+    pto = (po * to + (1.0 - po) * (1.0 - to)).clamp(eps, 1.0 - eps)
+    bceo = (-torch.log(pto)).mean()
+    tf = voi > 0
+    if tf.sum() > 0:
+        pi, ti = p[tf], t[tf]
+        alpha = (1.0 - ti.sum() / tf.sum()).clamp(0.25, 0.75)
+        pti = (pi * ti + (1.0 - pi) * (1.0 - ti)).clamp(eps, 1.0 - eps)
+        w = alpha * ti + (1.0 - alpha) * (1.0 - ti)
+        bce = (-torch.log(pti) * w).sum() / w.sum()
+        th = (pi > 0.5).to(p.dtype)
+        pth = (pi * th + (1.0 - pi) * (1.0 - th)).clamp(eps, 1.0 - eps)
+        boot = (-torch.log(pth)).mean()
+        return bceo + (1.0 - smoothing) * bce + smoothing * boot
+    return bceo
+
+
+def int_reg_refine_loss(dense, lobes, lesions, ctsses, freq_map, band_width=1e-2, smoothing=0.1):
+    """IntRegRefineLoss.__call__ (metrics.py:360-373) given the model output
+    (`dense` is both dense_outs and refined_dense_outs for DC3D)."""
+    probs = torch.sigmoid(dense)
+    reg = reg_loss_with_probs(probs, lobes, lesions, ctsses, freq_map, band_width)
+    # compute_seg_loss (metrics.py:331-358): pseudo label = (p>0.5 inside lobe) & lesion, zero if ctss==0
+    with torch.no_grad():
+        pd = probs.detach().clone()
+        pd[lobes == 0] = 0.0
+        pseudo = ((pd > 0.5) & (lesions > 0)).to(dense.dtype)
+        keep = torch.tensor([0.0 if float(c) < 1e-7 else 1.0 for c in ctsses], dtype=dense.dtype,
+                            device=dense.device).view(-1, 1, 1, 1, 1)
+        pseudo = pseudo * keep
+    seg = boot_bce(probs, pseudo, lobes > 0, smoothing)
+    return reg, seg

@@ -1,0 +1,249 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes
+are plain data (inputs + expected outputs) and are committed.  Usage:
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+How the reference is imported: dram/parts.py imports cleanly.  dram/models.py and
+dram/metrics.py import dgl / SimpleITK / cv2 / skimage at module level (never
+touched by DC3D or IntRegRefineLoss); those packages are not installed, so this
+process -- and only this process -- pre-seeds sys.modules with empty stand-in
+modules for them.  metrics.py hard-codes `.cuda()`; inside this process only,
+torch.Tensor.cuda is replaced by a no-op so the loss runs on CPU.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference/dram"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _import_reference():
+    warnings.filterwarnings("ignore", category=SyntaxWarning)
+    for name in ("dgl", "cv2", "SimpleITK", "skimage", "skimage.filters", "skimage.filters.thresholding",
+                 "skimage.exposure", "skimage.measure", "skimage.morphology", "skimage.transform",
+                 "tensorboardX", "seaborn"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sitk = sys.modules["SimpleITK"]
+    for c in ("sitkNearestNeighbor", "sitkLinear", "sitkGaussian", "sitkLabelGaussian", "sitkBSpline",
+              "sitkHammingWindowedSinc", "sitkCosineWindowedSinc", "sitkWelchWindowedSinc",
+              "sitkLanczosWindowedSinc"):
+        setattr(sitk, c, 0)
+    sys.modules["skimage.filters.thresholding"].threshold_otsu = None
+    sys.modules["skimage.filters"].threshold_otsu = None
+    sys.modules["skimage.exposure"].equalize_hist = None
+    sys.path.insert(0, REF)
+    import parts
+    import models
+    return parts, models
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def _block_case(tag, block, inputs, out_names, arrs, seed):
+    """Run a reference block fwd+bwd with fixed upstream grads, record everything."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in block.state_dict().items():
+        arrs[f"{tag}/sd/{k}"] = _np(v)
+    xs = []
+    for i, x in enumerate(inputs):
+        x = x.clone().requires_grad_(True)
+        xs.append(x)
+        arrs[f"{tag}/in{i}"] = _np(x)
+    outs = block(*xs)
+    if not isinstance(outs, tuple):
+        outs = (outs,)
+    loss = 0
+    for nm, o in zip(out_names, outs):
+        arrs[f"{tag}/out/{nm}"] = _np(o)
+        go = torch.randn(o.shape, generator=g)
+        arrs[f"{tag}/gout/{nm}"] = _np(go)
+        loss = loss + (o * go).sum()
+    loss.backward()
+    for i, x in enumerate(xs):
+        arrs[f"{tag}/gin{i}"] = _np(x.grad)
+    for k, p in block.named_parameters():
+        arrs[f"{tag}/gparam/{k}"] = _np(p.grad)
+    for k, v in block.state_dict().items():   # BN buffers after the training forward
+        if "running" in k or "num_batches" in k:
+            arrs[f"{tag}/sd_after/{k}"] = _np(v)
+    # eval-mode forward with the updated buffers
+    block.eval()
+    with torch.no_grad():
+        outs = block(*[x.detach() for x in xs])
+    if not isinstance(outs, tuple):
+        outs = (outs,)
+    for nm, o in zip(out_names, outs):
+        arrs[f"{tag}/eval/{nm}"] = _np(o)
+    block.train()
+
+
+def gen_blocks(parts):
+    arrs = {}
+    g = torch.Generator().manual_seed(1234)
+    shapes = {"even": (6, 10, 12), "odd": (7, 9, 11)}
+    for norm in ("bn", "ln", "in", "bnt", "bntna", "lnna", None):
+        for sname, (D, H, W) in shapes.items():
+            torch.manual_seed(11)
+            blk = parts.ConvPoolBlock5d([3, 4], [4, 6], 0, (3, 3), norm is None, (1, 1), 2, 2, 0,
+                                        dropout=0.0, norm_method=norm, act_method="relu")
+            # non-trivial affine parameters
+            for m in blk.modules():
+                if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.GroupNorm)) and m.weight is not None:
+                    m.weight.data = torch.rand(m.weight.shape, generator=g) + 0.5
+                    m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.3
+            x = torch.randn(2, 3, D, H, W, generator=g)
+            _block_case(f"convpool/{norm}/{sname}", blk, [x], ["y", "pooled"], arrs, seed=5)
+    for norm in ("bn", "ln"):
+        torch.manual_seed(12)
+        blk = parts.ConvBlock5d([5, 8], [8, 7], 0, 3, False, 1, 0.0, norm_method=norm)
+        x = torch.randn(2, 5, 5, 6, 9, generator=g)
+        _block_case(f"conv/{norm}", blk, [x], ["y"], arrs, seed=6)
+    torch.manual_seed(13)
+    blk = parts.ConvBlock5d([5, 8], [8, 7], 0, 3, True, 1, 0.0, lite=True)
+    x = torch.randn(2, 5, 5, 6, 9, generator=g)
+    _block_case("conv/lite", blk, [x], ["y"], arrs, seed=7)
+    for norm in ("bn", "in"):
+        torch.manual_seed(14)
+        blk = parts.UpsampleConvBlock5d([10, 5], [5, 4], 0, (2, 2, 2), (3, 3), False, (1, 1),
+                                        dropout=0.0, norm_method=norm)
+        lo = torch.randn(2, 6, 3, 5, 6, generator=g)
+        cat = torch.randn(2, 4, 7, 11, 13, generator=g)   # larger than 2x -> centre crop with ceil offset
+        _block_case(f"upconv/{norm}", blk, [lo, cat], ["y"], arrs, seed=8)
+    # crop_concat_5d alone
+    t1 = torch.randn(1, 2, 4, 5, 6, generator=g)
+    t2 = torch.randn(1, 3, 7, 6, 9, generator=g)
+    arrs["cropcat/t1"], arrs["cropcat/t2"] = _np(t1), _np(t2)
+    arrs["cropcat/out"] = _np(parts.crop_concat_5d(t1, t2))
+    _save("blocks", **arrs)
+
+
+SLIM = {  # same topology / flags as st_dram_ref.MODEL, channels / 8
+    "n_layers": 3,
+    "in_ch_list": [1, 8, 16, 32, 96, 48, 24],
+    "base_ch_list": [4, 8, 16, 32, 32, 16, 8],
+    "end_ch_list": [8, 16, 32, 64, 32, 16, 8],
+    "kernel_sizes": [(3, 3)] * 7,
+    "stacking": 3,
+    "padding_list": [(1, 1)] * 7,
+    "checkpoint_layers": [0, 1, 0, 1, 0, 1, 0],
+    "dropout": 0.0,
+    "upsample_ksize": (3, 3, 3),
+    "upsample_sf": (2, 2, 2),
+    "out_ch": 1,
+}
+
+
+def _model_case(models, cfg, norm, shape, tag, arrs, store_sd, n_grad_keys=None):
+    torch.manual_seed(0)
+    model = models.DC3D(**cfg, norm_method=norm) if norm != "bn" else models.DC3D(**cfg)
+    model.init(models.HeNorm(mode="fan_in"))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    if store_sd:
+        for k, v in sd0.items():
+            arrs[f"{tag}/sd/{k}"] = _np(v)
+    else:   # checksums only: the test re-creates the weights from the same seed
+        for k, v in sd0.items():
+            vf = v.double()
+            arrs[f"{tag}/sdsum/{k}"] = np.array([vf.sum().item(), (vf * vf).sum().item()])
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(1))
+    arrs[f"{tag}/x"] = _np(x)
+    model.eval()
+    with torch.no_grad():
+        arrs[f"{tag}/eval_out"] = _np(model(x)[0])
+    model.train()
+    d0, d1 = model(x, None)
+    assert d0 is d1
+    arrs[f"{tag}/train_out"] = _np(d0)
+    gout = torch.randn(d0.shape, generator=torch.Generator().manual_seed(2)) / d0.numel()
+    arrs[f"{tag}/gout"] = _np(gout)
+    (d0 * gout).sum().backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    keys = list(grads) if n_grad_keys is None else n_grad_keys
+    for k in keys:
+        arrs[f"{tag}/grad/{k}"] = _np(grads[k])
+    for k, gr in grads.items():
+        arrs[f"{tag}/gradnorm/{k}"] = np.array(gr.double().norm().item())
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrs[f"{tag}/sd_after/{k}"] = _np(v)
+
+
+def gen_models(models):
+    arrs = {}
+    _model_case(models, SLIM, "bn", (2, 1, 32, 32, 32), "slim_bn", arrs, store_sd=True)
+    few = ["top_layer.weight", "top_layer.bias", "ds_modules.0.conv_blocks.0.0.weight",
+           "ds_modules.1.conv_blocks.1.0.weight", "bg.conv_blocks.0.1.weight", "bg.conv_blocks.0.1.bias",
+           "us_modules.0.conv_blocks.0.0.weight", "us_modules.2.conv_blocks.1.0.weight"]
+    _model_case(models, SLIM, "ln", (2, 1, 24, 16, 32), "slim_ln", arrs, store_sd=True, n_grad_keys=few)
+    _model_case(models, SLIM, "in", (1, 1, 21, 18, 20), "slim_in_odd", arrs, store_sd=True,
+                n_grad_keys=few)   # floor-pool / crop / final resize
+    _save("dc3d_slim", **arrs)
+    # full-width st_dram_ref model: weights are re-created from seed 0 by the test (65 MB otherwise)
+    sys.path.insert(0, os.path.join(REF, "exp_settings"))
+    import st_dram_ref
+    cfg = dict(st_dram_ref.MODEL)
+    cfg.pop("method")
+    arrs = {}
+    small = ["top_layer.weight", "top_layer.bias", "ds_modules.0.conv_blocks.0.0.weight",
+             "ds_modules.0.conv_blocks.0.1.weight", "ds_modules.0.conv_blocks.0.1.bias",
+             "us_modules.2.conv_blocks.1.1.weight", "bg.conv_blocks.1.1.bias"]
+    _model_case(models, cfg, "bn", (1, 1, 32, 32, 32), "full_bn", arrs, store_sd=False, n_grad_keys=small)
+    _save("dc3d_full", **arrs)
+
+
+def gen_loss():
+    torch.Tensor.cuda = lambda self, *a, **k: self     # generator process only (metrics.py:136,173)
+    import metrics
+
+    class Obj:
+        ctss_frequency_map = {k: 1.0 / 6 for k in range(6)}
+        debug_path = "/tmp/_dram_golden_dbg"
+        epoch_n = 0
+    arrs = {}
+    g = torch.Generator().manual_seed(77)
+    N, S = 6, 12
+    zz, yy, xx = np.meshgrid(*[np.arange(S)] * 3, indexing="ij")
+    lobe = (((zz - S / 2 + .5) ** 2 + (yy - S / 2 + .5) ** 2 + (xx - S / 2 + .5) ** 2) < (0.45 * S) ** 2)
+    lobes = torch.from_numpy(lobe.astype(np.float32))[None, None].repeat(N, 1, 1, 1, 1)
+    images = torch.rand(N, 1, S, S, S, generator=g) * lobes
+    lesions = ((images > 0.7) & (lobes > 0)).float()
+    ctss = [float(n % 6) for n in range(N)]
+    dense = (torch.randn(N, 1, S, S, S, generator=g) * 2.0).requires_grad_(True)
+    loss_fn = metrics.IntRegRefineLoss(band_width=1e-2, smoothing=0.1)
+
+    def fake_model(imgs, lbs):
+        return dense, dense
+    fake_model.trace_path = None
+    reg, seg = loss_fn(fake_model, images, lobes, lesions, ctss, obj=Obj(), metas=None)
+    total = 2.0 * reg + 1.0 * seg
+    total.backward()
+    arrs.update(images=_np(images), lobes=_np(lobes), lesions=_np(lesions), ctss=np.array(ctss),
+                dense=_np(dense), reg=np.array(reg.item()), seg=np.array(seg.item()), gdense=_np(dense.grad))
+    _save("loss", **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    parts, models = _import_reference()
+    gen_blocks(parts)
+    gen_models(models)
+    gen_loss()

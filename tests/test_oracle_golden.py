@@ -1,0 +1,140 @@
+"""Pins the CPU oracle (oracle/dram_oracle.py) to golden vectors produced by
+running the reference itself (oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dram_oracle as O
+from oracle.make_golden import SLIM
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _sub(z, prefix):
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale)
+
+
+NORMS = ["bn", "ln", "in", "bnt", "bntna", "lnna", "None"]
+
+
+@pytest.mark.parametrize("norm", NORMS)
+@pytest.mark.parametrize("shape", ["even", "odd"])
+def test_convpool_block(golden_dir, norm, shape):
+    z = _load(golden_dir, "blocks")
+    tag = f"convpool/{norm}/{shape}/"
+    sd = {"b." + k: _t(v) for k, v in _sub(z, tag + "sd/").items()}
+    params, buffers = O.split_state_dict(sd)
+    for p in params.values():
+        p.requires_grad_(True)
+    x = _t(z[tag + "in0"]).requires_grad_(True)
+    nm = None if norm == "None" else norm
+    y = O.conv_norm_act_stack("b", 2, params, buffers, x, nm, True, [1, 1])
+    pooled = O.max_pool3d_2(y)
+    _close(y, z[tag + "out/y"])
+    _close(pooled, z[tag + "out/pooled"])
+    ((y * _t(z[tag + "gout/y"])).sum() + (pooled * _t(z[tag + "gout/pooled"])).sum()).backward()
+    _close(x.grad, z[tag + "gin0"], rtol=1e-4, atol=1e-5)
+    for k, g in _sub(z, tag + "gparam/").items():
+        _close(params["b." + k].grad, g, rtol=1e-4, atol=1e-5)
+    for k, v in _sub(z, tag + "sd_after/").items():
+        _close(buffers["b." + k].float(), v.astype(np.float32))
+    with torch.no_grad():
+        ye = O.conv_norm_act_stack("b", 2, params, buffers, x, nm, False, [1, 1])
+    _close(ye, z[tag + "eval/y"])
+
+
+@pytest.mark.parametrize("norm", ["bn", "in"])
+def test_upconv_block(golden_dir, norm):
+    z = _load(golden_dir, "blocks")
+    tag = f"upconv/{norm}/"
+    sd = {"b." + k: _t(v) for k, v in _sub(z, tag + "sd/").items()}
+    params, buffers = O.split_state_dict(sd)
+    lo, cat = _t(z[tag + "in0"]).requires_grad_(True), _t(z[tag + "in1"]).requires_grad_(True)
+    up = O.upsample_trilinear_ac(lo, scale_factor=(2, 2, 2))
+    y = O.conv_norm_act_stack("b", 2, params, buffers, O.crop_concat_5d(up, cat), norm, True, [1, 1])
+    _close(y, z[tag + "out/y"])
+    (y * _t(z[tag + "gout/y"])).sum().backward()
+    _close(lo.grad, z[tag + "gin0"], rtol=1e-4, atol=1e-5)
+    _close(cat.grad, z[tag + "gin1"], rtol=1e-4, atol=1e-5)
+
+
+def test_crop_concat(golden_dir):
+    z = _load(golden_dir, "blocks")
+    out = O.crop_concat_5d(_t(z["cropcat/t1"]), _t(z["cropcat/t2"]))
+    assert np.array_equal(out.numpy(), z["cropcat/out"])
+    assert O.crop_offsets((4, 5, 6), (7, 6, 9)) == (2, 1, 2)   # ceil((b-a)/2), parts.py:42-44
+
+
+def test_numpy_definitions_agree_with_torch_ops():
+    """First-principles numpy definitions == the ATen ops the oracle calls."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 5, 6, 7, generator=g)
+    w = torch.randn(4, 3, 3, 3, 3, generator=g)
+    b = torch.randn(4, generator=g)
+    _close(O.conv3d(x, w, b, 1), O.np_conv3d(x.numpy(), w.numpy(), b.numpy(), 1), rtol=1e-4, atol=1e-5)
+    xr = torch.relu(x)   # many ties at 0, like post-ReLU feature maps
+    out, idx = O.np_maxpool2(xr.numpy())
+    tout, tidx = torch.nn.functional.max_pool3d(xr, 2, 2, 0, return_indices=True)
+    assert np.array_equal(out, tout.numpy())
+    # flat input index -> window-local 0..7 index
+    D, H, W = xr.shape[2:]
+    ti = tidx.numpy()
+    tz, ty, tx = ti // (H * W), (ti // W) % H, ti % W
+    local = (tz % 2) * 4 + (ty % 2) * 2 + (tx % 2)
+    assert np.array_equal(local.astype(np.uint8), idx)
+    for size in [(10, 12, 14), (9, 13, 8), (5, 6, 7)]:
+        _close(O.upsample_trilinear_ac(x, size=size), O.np_trilinear_ac(x.numpy(), size), rtol=1e-5, atol=1e-6)
+    gam, bet = torch.rand(3) + 0.5, torch.randn(3)
+    yb, mean, var = O.np_batchnorm_train(x.numpy(), gam.numpy(), bet.numpy())
+    _close(torch.nn.functional.batch_norm(x, None, None, gam, bet, True, 0.1, O.EPS), yb, rtol=1e-4, atol=1e-5)
+    for G in (1, 3):
+        _close(torch.nn.functional.group_norm(x, G, gam, bet, O.EPS), O.np_groupnorm(x.numpy(), G, gam.numpy(), bet.numpy()),
+               rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,norm", [("slim_bn", "bn"), ("slim_ln", "ln"), ("slim_in_odd", "in")])
+def test_dc3d_slim(golden_dir, tag, norm):
+    z = _load(golden_dir, "dc3d_slim")
+    params, buffers = O.split_state_dict({k: _t(v) for k, v in _sub(z, tag + "/sd/").items()})
+    x = _t(z[tag + "/x"])
+    with torch.no_grad():
+        ev = O.dc3d_forward(SLIM, params, buffers, x, training=False, norm_method=norm)
+    _close(ev, z[tag + "/eval_out"], rtol=1e-4, atol=1e-5)
+    for p in params.values():
+        p.requires_grad_(True)
+    out = O.dc3d_forward(SLIM, params, buffers, x, training=True, norm_method=norm)
+    _close(out, z[tag + "/train_out"], rtol=1e-4, atol=1e-5)
+    (out * _t(z[tag + "/gout"])).sum().backward()
+    for k, g in _sub(z, tag + "/grad/").items():
+        _close(params[k].grad, g, rtol=1e-3, atol=1e-4)
+    for k, v in _sub(z, tag + "/sd_after/").items():
+        _close(buffers[k].double(), v.astype(np.float64), rtol=1e-5, atol=1e-6)
+    if norm == "bn":   # checkpointed blocks update their BN buffers twice per step
+        assert int(buffers["ds_modules.1.conv_blocks.0.1.num_batches_tracked"]) == 2
+        assert int(buffers["ds_modules.0.conv_blocks.0.1.num_batches_tracked"]) == 1
+
+
+def test_loss(golden_dir):
+    z = _load(golden_dir, "loss")
+    dense = _t(z["dense"]).requires_grad_(True)
+    freq = {k: 1.0 / 6 for k in range(6)}
+    reg, seg = O.int_reg_refine_loss(dense, _t(z["lobes"]), _t(z["lesions"]), list(z["ctss"]), freq, 1e-2, 0.1)
+    assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
+    assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
+    (2.0 * reg + 1.0 * seg).backward()
+    _close(dense.grad, z["gdense"], rtol=1e-4, atol=1e-6)
