@@ -1,0 +1,335 @@
+// 1x1x1 convolution with bias (the regression head), per-channel sums and the lobe-masked
+// mean, fp32 NCDHW, gfx950.
+//
+// Replaces the ATen dispatches of DC3D.top_layer = nn.Conv3d(64, out_ch, 1) (reference
+// dram/models.py:109-110,145) and of pooling_dense_features (models.py:37-49).
+//
+// the head is 64 -> 1 (a per-voxel 64-term dot product, 0.5 FLOP/B): HBM-bound, so
+// it is a streaming VALU kernel, not an MFMA GEMM.  Each thread owns 4 consecutive voxels
+// (float4 loads, 1 KiB per wave instruction) and walks the channel planes.
+#include "common.h"
+
+namespace dram {
+
+constexpr int MAXCO = 8;  // output channels handled per pass
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int Cin, int Cout, int co0, int nco, int64_t S) {
+    const int n = blockIdx.y;
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    if (e >= S) return;
+    const float* xp = x + (int64_t)n * Cin * S + e;
+    float acc[MAXCO][4];
+#pragma unroll
+    for (int o = 0; o < MAXCO; ++o) {
+        const float b = (bias && o < nco) ? bias[co0 + o] : 0.f;
+        acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = b;
+    }
+    for (int c = 0; c < Cin; ++c) {
+        float xv[4];
+        if (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + (int64_t)c * S);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        } else {
+            xv[0] = xp[(int64_t)c * S]; xv[1] = xv[2] = xv[3] = 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < MAXCO; ++o) {
+            if (o < nco) {
+                const float wv = w[(size_t)(co0 + o) * Cin + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[o][u] = fmaf(wv, xv[u], acc[o][u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXCO; ++o) {
+        if (o < nco) {
+            float* yp = y + ((int64_t)n * Cout + co0 + o) * S + e;
+            if (VEC) *reinterpret_cast<float4*>(yp) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+            else yp[0] = acc[o][0];
+        }
+    }
+}
+
+// dx[n,c,s] = sum_o w[o,c] * dy[n,o,s]   (Cout <= MAXCO per pass; accumulate over passes)
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int Cin, int Cout, int co0,
+                                                            int nco, int64_t S, int accumulate) {
+    const int n = blockIdx.y;
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    if (e >= S) return;
+    float g[MAXCO][4];
+#pragma unroll
+    for (int o = 0; o < MAXCO; ++o) {
+        g[o][0] = g[o][1] = g[o][2] = g[o][3] = 0.f;
+        if (o < nco) {
+            const float* p = dy + ((int64_t)n * Cout + co0 + o) * S + e;
+            if (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                g[o][0] = t.x; g[o][1] = t.y; g[o][2] = t.z; g[o][3] = t.w;
+            } else {
+                g[o][0] = p[0];
+            }
+        }
+    }
+    for (int c = 0; c < Cin; ++c) {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < MAXCO; ++o) {
+            if (o < nco) {
+                const float wv = w[(size_t)(co0 + o) * Cin + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = fmaf(wv, g[o][u], r[u]);
+            }
+        }
+        float* q = dx + ((int64_t)n * Cin + c) * S + e;
+        if (VEC) {
+            float4 t = make_float4(r[0], r[1], r[2], r[3]);
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(q);
+                t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+            }
+            *reinterpret_cast<float4*>(q) = t;
+        } else {
+            q[0] = accumulate ? q[0] + r[0] : r[0];
+        }
+    }
+}
+
+// Partial weight/bias gradients.  grid (nblk, N); block handles VPB voxels of sample n.
+// part[((n*nblk + blk) * Cout + o) * (Cin+1) + c] = sum_s dy[o,s]*x[c,s];  column Cin holds sum_s dy[o,s].
+constexpr int WG_VPT = 8;                 // voxels per thread
+constexpr int WG_VPB = 256 * WG_VPT;      // voxels per block
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ part, int Cin, int Cout, int64_t S,
+                                                            int nblk) {
+    __shared__ float red[4];
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int64_t base = (int64_t)blk * WG_VPB;
+    for (int o = 0; o < Cout; ++o) {
+        float g[WG_VPT];
+        float gs = 0.f;
+#pragma unroll
+        for (int u = 0; u < WG_VPT; ++u) {
+            const int64_t e = base + u * 256 + threadIdx.x;
+            g[u] = e < S ? dy[((int64_t)n * Cout + o) * S + e] : 0.f;
+            gs += g[u];
+        }
+        float* prow = part + (((size_t)n * nblk + blk) * Cout + o) * (Cin + 1);
+        gs = block_sum_256(gs, red);
+        if (threadIdx.x == 0) prow[Cin] = gs;
+        for (int c = 0; c < Cin; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < WG_VPT; ++u) {
+                const int64_t e = base + u * 256 + threadIdx.x;
+                if (e < S) s = fmaf(g[u], x[((int64_t)n * Cin + c) * S + e], s);
+            }
+            s = block_sum_256(s, red);
+            if (threadIdx.x == 0) prow[c] = s;
+        }
+    }
+}
+
+// out[j] = sum over `count` partial vectors of length L (fp64 accumulate, fixed order)
+__global__ void sum_partials_kernel(const float* __restrict__ part, int count, int L, float* __restrict__ dw,
+                                    float* __restrict__ dbias, int Cin, int Cout) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L) return;
+    double s = 0.0;
+    for (int p = 0; p < count; ++p) s += part[(size_t)p * L + j];
+    const int o = j / (Cin + 1), c = j % (Cin + 1);
+    if (c < Cin) { if (dw) dw[(size_t)o * Cin + c] = (float)s; }
+    else if (dbias) dbias[o] = (float)s;
+}
+
+// ---------------------------------------------------------------- per-channel sum (conv bias gradient)
+constexpr int CS_CHUNK = 8192;
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t S,
+                                                      int nchunks) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.y;
+    const int64_t beg = (int64_t)blockIdx.x * CS_CHUNK;
+    const int len = (int)((S - beg) < CS_CHUNK ? (S - beg) : CS_CHUNK);
+    const float* p = x + row * S + beg;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < len; e += 256) s += p[e];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) part[(size_t)row * nchunks + blockIdx.x] = s;
+}
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int C,
+                                            int nchunks) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n)
+        for (int ch = 0; ch < nchunks; ++ch) s += part[((size_t)n * C + c) * nchunks + ch];
+    out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------- masked mean
+// part[(row*nchunks+chunk)*2] = {sum x*m, sum m} over the chunk
+__global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                         float* __restrict__ part, int C, int64_t S, int nchunks) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.y;
+    const int n = (int)(row / C);
+    const int64_t beg = (int64_t)blockIdx.x * CS_CHUNK;
+    const int len = (int)((S - beg) < CS_CHUNK ? (S - beg) : CS_CHUNK);
+    const float* p = x + row * S + beg;
+    const float* q = m + (int64_t)n * S + beg;
+    float s = 0.f, ms = 0.f;
+    for (int e = threadIdx.x; e < len; e += 256) {
+        const float mv = q[e];
+        s = fmaf(p[e], mv, s);
+        ms += mv;
+    }
+    s = block_sum_256(s, red);
+    ms = block_sum_256(ms, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)row * nchunks + blockIdx.x) * 2] = s;
+        part[((size_t)row * nchunks + blockIdx.x) * 2 + 1] = ms;
+    }
+}
+__global__ void masked_mean_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                            float* __restrict__ msum, int N, int C, int nchunks) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N * C) return;
+    double s = 0.0, ms = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        s += part[((size_t)row * nchunks + ch) * 2];
+        ms += part[((size_t)row * nchunks + ch) * 2 + 1];
+    }
+    out[row] = (float)(s / ms);
+    if (row % C == 0) msum[row / C] = (float)ms;
+}
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dout,
+                                                              const float* __restrict__ m,
+                                                              const float* __restrict__ msum, float* __restrict__ dx,
+                                                              int C, int64_t S) {
+    const int64_t row = blockIdx.y;
+    const int n = (int)(row / C);
+    const float g = dout[row] / msum[n];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < S; e += stride) dx[row * S + e] = g * m[(int64_t)n * S + e];
+}
+
+static inline bool vec4_ok(const void* a, const void* b, int64_t S) {
+    return S % 4 == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+}
+
+}  // namespace dram
+
+using namespace dram;
+
+extern "C" int dram_conv3d_k1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin,
+                                  int Cout, int64_t S, void* stream) {
+    DRAM_REQUIRE(x && w && y, "conv3d_k1_fwd: null pointer");
+    DRAM_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && S > 0, "conv3d_k1_fwd: bad dimensions");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = vec4_ok(x, y, S);
+    for (int co0 = 0; co0 < Cout; co0 += MAXCO) {
+        const int nco = (Cout - co0) < MAXCO ? (Cout - co0) : MAXCO;
+        if (vec) {
+            dim3 grid((unsigned)cdiv64(S / 4, 256), N);
+            hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S);
+        } else {
+            dim3 grid((unsigned)cdiv64(S, 256), N);
+            hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S);
+        }
+    }
+    return check_launch("conv3d_k1_fwd");
+}
+
+extern "C" size_t dram_conv3d_k1_bwd_ws_bytes(int N, int Cin, int Cout, int64_t S) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || S <= 0) return 0;
+    const size_t nblk = (size_t)cdiv64(S, WG_VPB);
+    return (size_t)N * nblk * Cout * (Cin + 1) * sizeof(float);
+}
+
+extern "C" int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                                  void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S, void* stream) {
+    DRAM_REQUIRE(dy && x && w, "conv3d_k1_bwd: null pointer");
+    DRAM_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && S > 0, "conv3d_k1_bwd: bad dimensions");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        const bool vec = vec4_ok(dy, dx, S);
+        for (int co0 = 0; co0 < Cout; co0 += MAXCO) {
+            const int nco = (Cout - co0) < MAXCO ? (Cout - co0) : MAXCO;
+            if (vec) {
+                dim3 grid((unsigned)cdiv64(S / 4, 256), N);
+                hipLaunchKernelGGL(conv1x1_dgrad_kernel<true>, grid, dim3(256), 0, st, dy, w, dx, Cin, Cout, co0, nco, S, co0 > 0);
+            } else {
+                dim3 grid((unsigned)cdiv64(S, 256), N);
+                hipLaunchKernelGGL(conv1x1_dgrad_kernel<false>, grid, dim3(256), 0, st, dy, w, dx, Cin, Cout, co0, nco, S, co0 > 0);
+            }
+        }
+    }
+    if (dw || dbias) {
+        DRAM_REQUIRE(ws, "conv3d_k1_bwd: workspace is null");
+        if (ws_bytes < dram_conv3d_k1_bwd_ws_bytes(N, Cin, Cout, S)) {
+            set_error("conv3d_k1_bwd: workspace too small");
+            return DRAM_EWS;
+        }
+        const int nblk = (int)cdiv64(S, WG_VPB);
+        float* part = (float*)ws;
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk);
+        const int L = Cout * (Cin + 1);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 256)), dim3(256), 0, st, part, N * nblk, L, dw, dbias, Cin, Cout);
+    }
+    return check_launch("conv3d_k1_bwd");
+}
+
+extern "C" size_t dram_channel_sum_ws_bytes(int N, int C, int64_t S) {
+    if (N <= 0 || C <= 0 || S <= 0) return 0;
+    return (size_t)N * C * cdiv64(S, CS_CHUNK) * sizeof(float);
+}
+
+extern "C" int dram_channel_sum(const float* dy, float* dbias, void* ws, size_t ws_bytes, int N, int C, int64_t S,
+                                void* stream) {
+    DRAM_REQUIRE(dy && dbias && ws, "channel_sum: null pointer");
+    DRAM_REQUIRE(N > 0 && C > 0 && S > 0 && (int64_t)N * C <= 65535, "channel_sum: bad dimensions");
+    if (ws_bytes < dram_channel_sum_ws_bytes(N, C, S)) {
+        set_error("channel_sum: workspace too small");
+        return DRAM_EWS;
+    }
+    const int nch = (int)cdiv64(S, CS_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_sum_kernel, dim3(nch, N * C), dim3(256), 0, st, dy, (float*)ws, S, nch);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, dbias, N, C, nch);
+    return check_launch("channel_sum");
+}
+
+extern "C" size_t dram_masked_mean_ws_bytes(int N, int C, int64_t S) {
+    if (N <= 0 || C <= 0 || S <= 0) return 0;
+    return (size_t)N * C * cdiv64(S, CS_CHUNK) * 2 * sizeof(float);
+}
+
+extern "C" int dram_masked_mean_fwd(const float* x, const float* mask, float* out, float* msum, void* ws,
+                                    size_t ws_bytes, int N, int C, int64_t S, void* stream) {
+    DRAM_REQUIRE(x && mask && out && msum && ws, "masked_mean_fwd: null pointer");
+    DRAM_REQUIRE(N > 0 && C > 0 && S > 0 && (int64_t)N * C <= 65535, "masked_mean_fwd: bad dimensions");
+    if (ws_bytes < dram_masked_mean_ws_bytes(N, C, S)) {
+        set_error("masked_mean_fwd: workspace too small");
+        return DRAM_EWS;
+    }
+    const int nch = (int)cdiv64(S, CS_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_sum_kernel, dim3(nch, N * C), dim3(256), 0, st, x, mask, (float*)ws, C, S, nch);
+    hipLaunchKernelGGL(masked_mean_finalize_kernel, dim3(cdiv(N * C, 64)), dim3(64), 0, st, (const float*)ws, out, msum, N, C, nch);
+    return check_launch("masked_mean_fwd");
+}
+
+extern "C" int dram_masked_mean_bwd(const float* dout, const float* mask, const float* msum, float* dx, int N, int C,
+                                    int64_t S, void* stream) {
+    DRAM_REQUIRE(dout && mask && msum && dx, "masked_mean_bwd: null pointer");
+    DRAM_REQUIRE(N > 0 && C > 0 && S > 0 && (int64_t)N * C <= 65535, "masked_mean_bwd: bad dimensions");
+    const unsigned gx = (unsigned)(cdiv64(S, 256) < 1024 ? cdiv64(S, 256) : 1024);
+    hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, dout, mask, msum, dx, C, S);
+    return check_launch("masked_mean_bwd");
+}

@@ -1,0 +1,294 @@
+// 2x2x2 max-pool, trilinear (align_corners=True) resize and crop-concat for fp32 NCDHW, gfx950.
+//
+// Replaces the ATen max_pool3d / upsample_trilinear3d / cat dispatches (+ backward) of
+// reference dram/parts.py:191 (MaxPool3d(2,2,0)), parts.py:149 and models.py:146
+// (nn.Upsample trilinear, align_corners=True) and parts.py:37-46 (crop_concat_5d).
+//
+// All HBM-bound streaming kernels: one thread per output element along x (coalesced
+// 256-byte wave stores), reads are row segments that the wave covers contiguously.
+#include "common.h"
+
+namespace dram {
+
+// ---------------------------------------------------------------- max pool
+// thread per pooled output; idx = dz*4 + dy*2 + dx of the FIRST maximum in (z,y,x) scan
+// order (ATen: `if (val > maxval || isnan(val))`), which is where the gradient goes.
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           uint8_t* __restrict__ idx, int D, int H, int W, int Do,
+                                                           int Ho, int Wo) {
+    const int64_t plane = blockIdx.y;  // n*C + c
+    const int So = Do * Ho * Wo;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= So) return;
+    const int xo = e % Wo, yo = (e / Wo) % Ho, zo = e / (Wo * Ho);
+    const float* p = x + plane * ((int64_t)D * H * W) + ((int64_t)(2 * zo) * H + 2 * yo) * W + 2 * xo;
+    float best = p[0];
+    int bi = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+        const float v = p[((int64_t)dz * H + dy) * W + dx];
+        if (v > best || v != v) { best = v; bi = k; }
+    }
+    out[plane * So + e] = best;
+    idx[plane * So + e] = (uint8_t)bi;
+}
+
+// thread per INPUT element (coalesced dx stores); positions beyond the floor-cropped extent get 0.
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dout,
+                                                           const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                           int D, int H, int W, int Do, int Ho, int Wo) {
+    const int64_t plane = blockIdx.y;
+    const int S = D * H * W;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    const int xi = e % W, yi = (e / W) % H, zi = e / (W * H);
+    const int xo = xi >> 1, yo = yi >> 1, zo = zi >> 1;
+    float g = 0.f;
+    if (xo < Wo && yo < Ho && zo < Do) {
+        const int64_t o = plane * ((int64_t)Do * Ho * Wo) + ((int64_t)zo * Ho + yo) * Wo + xo;
+        const int local = ((zi & 1) << 2) | ((yi & 1) << 1) | (xi & 1);
+        if (idx[o] == local) g = dout[o];
+    }
+    dx[plane * (int64_t)S + e] = g;
+}
+
+// ---------------------------------------------------------------- trilinear, align_corners=True
+// ATen (UpSample.h area_pixel_compute_scale / compute_source_index, align_corners branch):
+//   scale = out > 1 ? (in-1)/(out-1) : 0 (fp32);  src = scale*dst;  i0 = (int)src;
+//   i1 = i0 + (i0 < in-1);  l1 = src - i0;  l0 = 1 - l1.
+struct Axis {
+    int in, out;
+    float scale;
+};
+
+__device__ __forceinline__ void src_index(const Axis& a, int o, int& i0, int& i1, float& l0, float& l1) {
+    const float src = a.scale * (float)o;
+    i0 = (int)src;
+    if (i0 > a.in - 1) i0 = a.in - 1;
+    i1 = i0 + (i0 < a.in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            Axis az, Axis ay, Axis ax) {
+    const int64_t plane = blockIdx.y;
+    const int So = az.out * ay.out * ax.out;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= So) return;
+    const int xo = e % ax.out, yo = (e / ax.out) % ay.out, zo = e / (ax.out * ay.out);
+    int z0, z1, y0, y1, x0, x1;
+    float a0, a1, b0, b1, c0, c1;
+    src_index(az, zo, z0, z1, a0, a1);
+    src_index(ay, yo, y0, y1, b0, b1);
+    src_index(ax, xo, x0, x1, c0, c1);
+    const float* p = x + plane * ((int64_t)az.in * ay.in * ax.in);
+    const int H = ay.in, W = ax.in;
+    auto at = [&](int z, int yy, int xx) { return p[((int64_t)z * H + yy) * W + xx]; };
+    const float v = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+                    a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+    y[plane * (int64_t)So + e] = v;
+}
+
+// Adjoint in gather form.  For input index i the outputs that touch it form the contiguous range
+// [lo, hi] = {o : i0(o) in {i-1, i}}; each contributes l0(o) if i0(o)==i plus l1(o) if i1(o)==i.
+__device__ __forceinline__ void touch_range(const Axis& a, int i, int& lo, int& hi) {
+    if (a.out <= 1 || a.scale <= 0.f) { lo = 0; hi = a.out - 1; return; }
+    // conservative bounds from the inverse map, then clamp
+    const float inv = 1.f / a.scale;
+    lo = (int)floorf((float)(i - 1) * inv) - 1;
+    hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > a.out - 1) hi = a.out - 1;
+}
+
+__device__ __forceinline__ float touch_weight(const Axis& a, int o, int i) {
+    int i0, i1;
+    float l0, l1;
+    src_index(a, o, i0, i1, l0, l1);
+    float w = 0.f;
+    if (i0 == i) w += l0;
+    if (i1 == i) w += l1;   // when i1 == i0 (last row) both weights land on the same input, as in ATen's backward
+    return w;
+}
+
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                            Axis az, Axis ay, Axis ax) {
+    const int64_t plane = blockIdx.y;
+    const int S = az.in * ay.in * ax.in;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    const int xi = e % ax.in, yi = (e / ax.in) % ay.in, zi = e / (ax.in * ay.in);
+    int zl, zh, yl, yh, xl, xh;
+    touch_range(az, zi, zl, zh);
+    touch_range(ay, yi, yl, yh);
+    touch_range(ax, xi, xl, xh);
+    const float* p = dy + plane * ((int64_t)az.out * ay.out * ax.out);
+    float acc = 0.f;
+    for (int zo = zl; zo <= zh; ++zo) {
+        const float wz = touch_weight(az, zo, zi);
+        if (wz == 0.f) continue;
+        for (int yo = yl; yo <= yh; ++yo) {
+            const float wy = touch_weight(ay, yo, yi);
+            if (wy == 0.f) continue;
+            const float* row = p + ((int64_t)zo * ay.out + yo) * ax.out;
+            float racc = 0.f;
+            for (int xo = xl; xo <= xh; ++xo) {
+                const float wx = touch_weight(ax, xo, xi);
+                racc += wx * row[xo];
+            }
+            acc += wz * wy * racc;
+        }
+    }
+    dx[plane * (int64_t)S + e] = acc;
+}
+
+// ---------------------------------------------------------------- crop + concat
+__global__ __launch_bounds__(256) void crop_concat_fwd_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                                              float* __restrict__ out, int C1, int C2, int D, int H,
+                                                              int W, int D2, int H2, int W2, int oz, int oy, int ox) {
+    const int Ct = C1 + C2;
+    const int64_t plane = blockIdx.y;  // n*Ct + c
+    const int n = (int)(plane / Ct), c = (int)(plane % Ct);
+    const int S = D * H * W;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    float v;
+    if (c < C1) {
+        v = t1[((int64_t)n * C1 + c) * S + e];
+    } else {
+        const int xi = e % W, yi = (e / W) % H, zi = e / (W * H);
+        v = t2[((int64_t)n * C2 + (c - C1)) * ((int64_t)D2 * H2 * W2) + ((int64_t)(zi + oz) * H2 + yi + oy) * W2 + xi + ox];
+    }
+    out[plane * (int64_t)S + e] = v;
+}
+
+__global__ __launch_bounds__(256) void crop_concat_bwd1_kernel(const float* __restrict__ dout, float* __restrict__ dt1,
+                                                               int C1, int C2, int S) {
+    const int64_t plane = blockIdx.y;  // n*C1 + c
+    const int n = (int)(plane / C1), c = (int)(plane % C1);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    dt1[plane * (int64_t)S + e] = dout[((int64_t)n * (C1 + C2) + c) * S + e];
+}
+
+__global__ __launch_bounds__(256) void crop_concat_bwd2_kernel(const float* __restrict__ dout, float* __restrict__ dt2,
+                                                               int C1, int C2, int D, int H, int W, int D2, int H2,
+                                                               int W2, int oz, int oy, int ox) {
+    const int64_t plane = blockIdx.y;  // n*C2 + c
+    const int n = (int)(plane / C2), c = (int)(plane % C2);
+    const int S2 = D2 * H2 * W2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S2) return;
+    const int xi = e % W2 - ox, yi = (e / W2) % H2 - oy, zi = e / (W2 * H2) - oz;
+    float v = 0.f;
+    if (xi >= 0 && xi < W && yi >= 0 && yi < H && zi >= 0 && zi < D)
+        v = dout[((int64_t)n * (C1 + C2) + C1 + c) * ((int64_t)D * H * W) + ((int64_t)zi * H + yi) * W + xi];
+    dt2[plane * (int64_t)S2 + e] = v;
+}
+
+static inline Axis make_axis(int in, int out) {
+    Axis a;
+    a.in = in;
+    a.out = out;
+    a.scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return a;
+}
+
+static int check_planes(const char* who, int64_t planes, int64_t S) {
+    DRAM_REQUIRE(planes > 0 && planes <= 65535, "%s: N*C=%lld out of range (1..65535)", who, (long long)planes);
+    DRAM_REQUIRE(S > 0 && S < 0x7fffffffLL, "%s: spatial size out of range", who);
+    return DRAM_OK;
+}
+
+}  // namespace dram
+
+using namespace dram;
+
+extern "C" int dram_maxpool3d_2_fwd(const float* x, float* out, uint8_t* idx, int N, int C, int D, int H, int W,
+                                    void* stream) {
+    DRAM_REQUIRE(x && out && idx, "maxpool3d_2_fwd: null pointer");
+    DRAM_REQUIRE(D >= 2 && H >= 2 && W >= 2, "maxpool3d_2_fwd: spatial size below the 2x2x2 window");
+    int rc = check_planes("maxpool3d_2_fwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    dim3 grid(cdiv(Do * Ho * Wo, 256), N * C);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, idx, D, H, W, Do, Ho, Wo);
+    return check_launch("maxpool3d_2_fwd");
+}
+
+extern "C" int dram_maxpool3d_2_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
+                                    int W, void* stream) {
+    DRAM_REQUIRE(dout && idx && dx, "maxpool3d_2_bwd: null pointer");
+    DRAM_REQUIRE(D >= 2 && H >= 2 && W >= 2, "maxpool3d_2_bwd: spatial size below the 2x2x2 window");
+    int rc = check_planes("maxpool3d_2_bwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    dim3 grid(cdiv(D * H * W, 256), N * C);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, idx, dx, D, H, W, D / 2,
+                       H / 2, W / 2);
+    return check_launch("maxpool3d_2_bwd");
+}
+
+extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, int C, int D, int H, int W, int Do,
+                                              int Ho, int Wo, void* stream) {
+    DRAM_REQUIRE(x && y, "upsample_trilinear_ac_fwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_fwd: bad sizes");
+    int rc = check_planes("upsample_trilinear_ac_fwd", (int64_t)N * C, (int64_t)Do * Ho * Wo);
+    if (rc) return rc;
+    dim3 grid(cdiv(Do * Ho * Wo, 256), N * C);
+    hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
+                       make_axis(H, Ho), make_axis(W, Wo));
+    return check_launch("upsample_trilinear_ac_fwd");
+}
+
+extern "C" int dram_upsample_trilinear_ac_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, int Do,
+                                              int Ho, int Wo, void* stream) {
+    DRAM_REQUIRE(dy && dx, "upsample_trilinear_ac_bwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_bwd: bad sizes");
+    int rc = check_planes("upsample_trilinear_ac_bwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    dim3 grid(cdiv(D * H * W, 256), N * C);
+    hipLaunchKernelGGL(trilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, make_axis(D, Do),
+                       make_axis(H, Ho), make_axis(W, Wo));
+    return check_launch("upsample_trilinear_ac_bwd");
+}
+
+static int check_crop(const char* who, int D, int H, int W, int D2, int H2, int W2, int oz, int oy, int ox) {
+    DRAM_REQUIRE(oz >= 0 && oy >= 0 && ox >= 0 && oz + D <= D2 && oy + H <= H2 && ox + W <= W2,
+                 "%s: crop window outside the second tensor", who);
+    return DRAM_OK;
+}
+
+extern "C" int dram_crop_concat_fwd(const float* t1, const float* t2, float* out, int N, int C1, int C2, int D, int H,
+                                    int W, int D2, int H2, int W2, int oz, int oy, int ox, void* stream) {
+    DRAM_REQUIRE(t1 && t2 && out, "crop_concat_fwd: null pointer");
+    DRAM_REQUIRE(C1 > 0 && C2 > 0, "crop_concat_fwd: bad channel counts");
+    int rc = check_planes("crop_concat_fwd", (int64_t)N * (C1 + C2), (int64_t)D * H * W);
+    if (rc) return rc;
+    if ((rc = check_crop("crop_concat_fwd", D, H, W, D2, H2, W2, oz, oy, ox))) return rc;
+    dim3 grid(cdiv(D * H * W, 256), N * (C1 + C2));
+    hipLaunchKernelGGL(crop_concat_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, t1, t2, out, C1, C2, D, H, W,
+                       D2, H2, W2, oz, oy, ox);
+    return check_launch("crop_concat_fwd");
+}
+
+extern "C" int dram_crop_concat_bwd(const float* dout, float* dt1, float* dt2, int N, int C1, int C2, int D, int H,
+                                    int W, int D2, int H2, int W2, int oz, int oy, int ox, void* stream) {
+    DRAM_REQUIRE(dout, "crop_concat_bwd: null pointer");
+    DRAM_REQUIRE(C1 > 0 && C2 > 0, "crop_concat_bwd: bad channel counts");
+    int rc = check_planes("crop_concat_bwd", (int64_t)N * (C1 + C2), (int64_t)D2 * H2 * W2);
+    if (rc) return rc;
+    if ((rc = check_crop("crop_concat_bwd", D, H, W, D2, H2, W2, oz, oy, ox))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dt1) {
+        dim3 grid(cdiv(D * H * W, 256), N * C1);
+        hipLaunchKernelGGL(crop_concat_bwd1_kernel, grid, dim3(256), 0, st, dout, dt1, C1, C2, D * H * W);
+    }
+    if (dt2) {
+        dim3 grid(cdiv(D2 * H2 * W2, 256), N * C2);
+        hipLaunchKernelGGL(crop_concat_bwd2_kernel, grid, dim3(256), 0, st, dout, dt2, C1, C2, D, H, W, D2, H2, W2,
+                           oz, oy, ox);
+    }
+    return check_launch("crop_concat_bwd");
+}

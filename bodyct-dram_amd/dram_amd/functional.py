@@ -1,0 +1,386 @@
+"""torch.autograd Functions over the libdram_hip.so C ABI.
+
+PyTorch is plumbing here: it owns the HBM buffers (caching allocator), the HIP
+stream and the autograd tape; every forward / backward computation is a call
+into the hand-written gfx950 kernels.  All tensors are fp32 NCDHW contiguous.
+There is no fallback: CPU tensors raise.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import call
+
+NORM_BATCH, NORM_GROUP = 0, 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the DRAM HIP path only runs on a ROCm device "
+                           f"(there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim}-d tensor, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def crop_offsets(small, big):
+    """Start offsets of crop_concat_5d's centre crop: ceil((b - a) / 2) (reference parts.py:42-44)."""
+    return tuple(int(math.ceil((b - a) / 2)) for a, b in zip(small, big))
+
+
+# --------------------------------------------------------------------------- conv 3x3x3
+def _pack(w, mode):
+    co, ci = w.shape[0], w.shape[1]
+    wt = torch.empty(27 * ci * co, dtype=torch.float32, device=w.device)
+    call("dram_conv3d_k3_pack_weights", _p(w), _p(wt), co, ci, mode, _stream())
+    return wt
+
+
+class Conv3dK3Fn(Function):
+    """y = conv3d(cat(x1, crop(x2)), w, bias), k=3, stride 1, zero pad 1.  x2 may be None.
+    (nn.Conv3d of reference parts.py:95,105,133,142,177,185; crop_concat_5d of parts.py:153 fused.)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias):
+        x1 = _chk(x1, "conv3d input", 5)
+        w = _chk(w, "conv3d weight", 5)
+        N, C1, D, H, W = x1.shape
+        Co, Ci = w.shape[0], w.shape[1]
+        if tuple(w.shape[2:]) != (3, 3, 3):
+            raise ValueError(f"Conv3dK3Fn: kernel {tuple(w.shape[2:])} is not 3x3x3")
+        if x2 is not None:
+            x2 = _chk(x2, "conv3d second input", 5)
+            C2, D2, H2, W2 = x2.shape[1:]
+            if x2.shape[0] != N:
+                raise ValueError("conv3d: batch sizes of the two inputs differ")
+            if not (D <= D2 and H <= H2 and W <= W2):
+                raise ValueError("conv3d: the second (skip) tensor must be at least as large as the first")
+            oz, oy, ox = crop_offsets((D, H, W), (D2, H2, W2))
+        else:
+            C2 = D2 = H2 = W2 = oz = oy = ox = 0
+        if C1 + C2 != Ci:
+            raise ValueError(f"conv3d: input has {C1 + C2} channels, weight expects {Ci}")
+        if bias is not None:
+            bias = _chk(bias, "conv3d bias", 1)
+        wt = _pack(w, 0)
+        y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x1.device)
+        call("dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
+             _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
+        ctx.save_for_backward(x1, x2, w)
+        ctx.has_bias = bias is not None
+        ctx.geom = (C2, D2, H2, W2, oz, oy, ox)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        dy = _chk(dy, "conv3d grad_output", 5)
+        N, C1, D, H, W = x1.shape
+        Co, Ci = w.shape[0], w.shape[1]
+        C2, D2, H2, W2, oz, oy, ox = ctx.geom
+        st = _stream()
+        dx1 = dx2 = dw = db = None
+        need1 = ctx.needs_input_grad[0]
+        need2 = x2 is not None and ctx.needs_input_grad[1]
+        if need1 or need2:
+            wt = _pack(w, 1)   # filter of the transposed conv: [27][Co][Ci]
+            dx1 = torch.empty_like(x1)
+            if x2 is not None:
+                full = (D2, H2, W2) == (D, H, W)
+                dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
+            call("dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
+                 _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
+            if not need1:
+                dx1 = None
+            if not need2:
+                dx2 = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            nbytes = _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)
+            ws = _ws(nbytes, dy.device)
+            call("dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
+                 _p(ws), ws.numel(), N, Co, D, H, W, st)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            S = D * H * W
+            db = torch.empty(Co, dtype=torch.float32, device=dy.device)
+            ws = _ws(_lib.lib.dram_channel_sum_ws_bytes(N, Co, S), dy.device)
+            call("dram_channel_sum", _p(dy), _p(db), _p(ws), ws.numel(), N, Co, S, st)
+        return dx1, dx2, dw, db
+
+
+def conv3d_k3(x, w, bias=None, skip=None):
+    return Conv3dK3Fn.apply(x, skip, w, bias)
+
+
+# --------------------------------------------------------------------------- conv 1x1x1 (+bias)
+class Conv3dK1Fn(Function):
+    """The regression head top_layer = nn.Conv3d(C, out_ch, 1) (reference models.py:109-110,145)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = _chk(x, "conv1x1 input", 5)
+        w = _chk(w, "conv1x1 weight", 5)
+        N, Ci, D, H, W = x.shape
+        Co = w.shape[0]
+        if w.shape[1] != Ci or tuple(w.shape[2:]) != (1, 1, 1):
+            raise ValueError(f"conv1x1: weight {tuple(w.shape)} does not match input channels {Ci}")
+        if bias is not None:
+            bias = _chk(bias, "conv1x1 bias", 1)
+        y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x.device)
+        call("dram_conv3d_k1_fwd", _p(x), _p(w), _p(bias), _p(y), N, Ci, Co, D * H * W, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _chk(dy, "conv1x1 grad_output", 5)
+        N, Ci, D, H, W = x.shape
+        Co, S = w.shape[0], D * H * W
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(Co, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        ws = _ws(_lib.lib.dram_conv3d_k1_bwd_ws_bytes(N, Ci, Co, S), x.device)
+        call("dram_conv3d_k1_bwd", _p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), _p(ws), ws.numel(),
+             N, Ci, Co, S, _stream())
+        return dx, dw, db
+
+
+def conv3d_k1(x, w, bias=None):
+    return Conv3dK1Fn.apply(x, w, bias)
+
+
+# --------------------------------------------------------------------------- norm (+ReLU)
+class NormActFn(Function):
+    """BatchNorm3d / GroupNorm with optional fused ReLU (normal_wrapper + act_wrapper,
+    reference parts.py:17-35,48-54).  `running_mean/var` are updated in place when given
+    (training BatchNorm with track_running_stats)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, kind, groups, use_batch_stats, momentum, eps, relu):
+        x = _chk(x, "norm input")
+        if x.dim() < 3:
+            raise ValueError("norm: expected (N, C, *spatial)")
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        dev = x.device
+        nstat = C if kind == NORM_BATCH else N * groups
+        y = torch.empty_like(x)
+        save_mean = torch.empty(nstat, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(nstat, dtype=torch.float32, device=dev)
+        rowcoef = torch.empty(2 * N * C, dtype=torch.float32, device=dev)
+        st = _stream()
+        if gamma is not None:
+            gamma = _chk(gamma, "norm weight", 1)
+        if beta is not None:
+            beta = _chk(beta, "norm bias", 1)
+        if use_batch_stats:
+            ws = _ws(_lib.lib.dram_norm_ws_bytes(N, C, S), dev)
+            call("dram_norm_fwd_train", _p(x), _p(gamma), _p(beta), _p(y), _p(save_mean), _p(save_rstd), _p(rowcoef),
+                 _p(running_mean), _p(running_var), float(momentum), float(eps), kind, groups, int(relu),
+                 N, C, S, _p(ws), ws.numel(), st)
+        else:
+            call("dram_bn_fwd_eval", _p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y),
+                 _p(save_mean), _p(save_rstd), _p(rowcoef), float(eps), int(relu), N, C, S, st)
+        ctx.save_for_backward(x, gamma, save_mean, save_rstd, rowcoef)
+        ctx.cfg = (kind, groups, bool(use_batch_stats), bool(relu), beta is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, save_mean, save_rstd, rowcoef = ctx.saved_tensors
+        kind, groups, batch_stats, relu, has_beta = ctx.cfg
+        dy = _chk(dy, "norm grad_output")
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_beta else None
+        ws = _ws(_lib.lib.dram_norm_ws_bytes(N, C, S), dev)
+        call("dram_norm_bwd", _p(dy), _p(x), _p(gamma), _p(save_mean), _p(save_rstd), _p(rowcoef), _p(dx),
+             _p(dgamma), _p(dbeta), kind, groups, int(relu), int(batch_stats), N, C, S, _p(ws), ws.numel(), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def norm_act(x, gamma, beta, running_mean, running_var, kind, groups, use_batch_stats, momentum, eps, relu):
+    return NormActFn.apply(x, gamma, beta, running_mean, running_var, kind, groups, use_batch_stats, momentum, eps, relu)
+
+
+class ReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "relu input")
+        y = torch.empty_like(x)
+        call("dram_relu_fwd", _p(x), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _chk(dy, "relu grad_output")
+        dx = torch.empty_like(dy)
+        call("dram_relu_bwd", _p(dy), _p(y), _p(dx), dy.numel(), _stream())
+        return dx
+
+
+def relu(x):
+    return ReLUFn.apply(x)
+
+
+# --------------------------------------------------------------------------- max pool 2x2x2
+class MaxPool2Fn(Function):
+    """nn.MaxPool3d(2, 2, 0) (reference parts.py:191)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "maxpool input", 5)
+        N, C, D, H, W = x.shape
+        out = torch.empty((N, C, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+        call("dram_maxpool3d_2_fwd", _p(x), _p(out), _p(idx), N, C, D, H, W, _stream())
+        ctx.save_for_backward(idx)
+        ctx.in_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = _chk(dout, "maxpool grad_output", 5)
+        N, C, D, H, W = ctx.in_shape
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=dout.device)
+        call("dram_maxpool3d_2_bwd", _p(dout), _p(idx), _p(dx), N, C, D, H, W, _stream())
+        return dx
+
+
+def max_pool3d_2(x):
+    return MaxPool2Fn.apply(x)
+
+
+# --------------------------------------------------------------------------- trilinear resize
+class TrilinearACFn(Function):
+    """nn.Upsample(mode='trilinear', align_corners=True) (reference parts.py:149, models.py:146)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _chk(x, "upsample input", 5)
+        N, C, D, H, W = x.shape
+        Do, Ho, Wo = (int(s) for s in size)
+        y = torch.empty((N, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+        call("dram_upsample_trilinear_ac_fwd", _p(x), _p(y), N, C, D, H, W, Do, Ho, Wo, _stream())
+        ctx.shapes = (N, C, D, H, W, Do, Ho, Wo)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        N, C, D, H, W, Do, Ho, Wo = ctx.shapes
+        dy = _chk(dy, "upsample grad_output", 5)
+        dx = torch.empty((N, C, D, H, W), dtype=torch.float32, device=dy.device)
+        call("dram_upsample_trilinear_ac_bwd", _p(dy), _p(dx), N, C, D, H, W, Do, Ho, Wo, _stream())
+        return dx, None
+
+
+def upsample_trilinear_ac(x, size=None, scale_factor=None):
+    if size is None:
+        if scale_factor is None:
+            raise ValueError("either size or scale_factor should be defined")
+        sf = scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * 3
+        # torch: output = floor(input * scale_factor)
+        size = tuple(int(math.floor(float(d) * float(s))) for d, s in zip(x.shape[2:], sf))
+    elif not isinstance(size, (tuple, list, torch.Size)):
+        size = (size,) * 3
+    return TrilinearACFn.apply(x, tuple(size))
+
+
+# --------------------------------------------------------------------------- crop + concat
+class CropConcatFn(Function):
+    """crop_concat_5d (reference parts.py:37-46)."""
+
+    @staticmethod
+    def forward(ctx, t1, t2):
+        t1 = _chk(t1, "crop_concat t1", 5)
+        t2 = _chk(t2, "crop_concat t2", 5)
+        N, C1, D, H, W = t1.shape
+        C2, D2, H2, W2 = t2.shape[1:]
+        oz, oy, ox = crop_offsets((D, H, W), (D2, H2, W2))
+        out = torch.empty((N, C1 + C2, D, H, W), dtype=torch.float32, device=t1.device)
+        call("dram_crop_concat_fwd", _p(t1), _p(t2), _p(out), N, C1, C2, D, H, W, D2, H2, W2, oz, oy, ox, _stream())
+        ctx.geom = (N, C1, C2, D, H, W, D2, H2, W2, oz, oy, ox)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        N, C1, C2, D, H, W, D2, H2, W2, oz, oy, ox = ctx.geom
+        dout = _chk(dout, "crop_concat grad_output", 5)
+        dt1 = torch.empty((N, C1, D, H, W), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        dt2 = torch.empty((N, C2, D2, H2, W2), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        call("dram_crop_concat_bwd", _p(dout), _p(dt1), _p(dt2), N, C1, C2, D, H, W, D2, H2, W2, oz, oy, ox, _stream())
+        return dt1, dt2
+
+
+def crop_concat(t1, t2):
+    return CropConcatFn.apply(t1, t2)
+
+
+# --------------------------------------------------------------------------- lobe-masked mean
+class MaskedMeanFn(Function):
+    """sum(x*m)/sum(m) per (n, c) (pooling_dense_features default branch, reference models.py:45-47)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x = _chk(x, "masked_mean input", 5)
+        mask = _chk(mask, "masked_mean mask", 5)
+        N, C = x.shape[:2]
+        S = x.numel() // (N * C)
+        if mask.shape[0] != N or mask.shape[1] != 1 or mask.numel() != N * S:
+            raise ValueError(f"masked_mean: mask {tuple(mask.shape)} does not broadcast over {tuple(x.shape)}")
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        msum = torch.empty(N, dtype=torch.float32, device=x.device)
+        ws = _ws(_lib.lib.dram_masked_mean_ws_bytes(N, C, S), x.device)
+        call("dram_masked_mean_fwd", _p(x), _p(mask), _p(out), _p(msum), _p(ws), ws.numel(), N, C, S, _stream())
+        ctx.save_for_backward(mask, msum)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        mask, msum = ctx.saved_tensors
+        dout = _chk(dout, "masked_mean grad_output", 2)
+        N, C = ctx.shape[:2]
+        S = mask.numel() // N
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        call("dram_masked_mean_bwd", _p(dout), _p(mask), _p(msum), _p(dx), N, C, S, _stream())
+        return dx, None
+
+
+def masked_mean(x, mask):
+    return MaskedMeanFn.apply(x, mask)

@@ -1,0 +1,178 @@
+/*
+ * dram_hip.h -- C ABI of libdram_hip.so: the MI355X (gfx950) kernels under the
+ * DRAM DC3D forward/backward hot path.
+ *
+ * The reference (DIAGNijmegen/bodyct-dram) has no FFI: its hot path is the set
+ * of ATen ops that dram/parts.py and dram/models.py dispatch.  Each entry point
+ * below replaces one of those dispatches; the comment above it cites the
+ * reference line that issues the op.  The Python host side
+ * (bodyct-dram_amd/dram_amd/) binds these with ctypes; INTEGRATION.md shows the
+ * stub.
+ *
+ * Conventions
+ *   - every tensor is fp32, NCDHW, contiguous, in device (HBM) memory;
+ *   - S = D*H*W; "row" = one (n, c) pair = S contiguous floats;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on
+ *     it and performs no allocation and no host synchronisation;
+ *   - `ws` is caller-provided device scratch of at least the size returned by
+ *     the matching *_ws_bytes() query (may be NULL when that size is 0);
+ *   - return value: 0 on success, a negative DRAM_E* code otherwise (nothing is
+ *     launched on an argument error); dram_last_error() gives the message of
+ *     the calling thread's last failure.
+ */
+#ifndef DRAM_HIP_H
+#define DRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRAM_OK 0
+#define DRAM_EINVAL (-1)  /* bad shape / null pointer / unsupported argument */
+#define DRAM_EWS (-2)     /* workspace too small */
+#define DRAM_EHIP (-3)    /* HIP runtime error at launch */
+
+/* norm kinds for dram_norm_* (reference parts.py:17-35 normal_wrapper) */
+#define DRAM_NORM_BATCH 0 /* statistics per channel over (N, D, H, W): "bn", "bnt", "bntna", "sbn" */
+#define DRAM_NORM_GROUP 1 /* statistics per (sample, group): "ln"/"lnna" (G=1), "in" (G=C) */
+
+const char* dram_last_error(void);
+int dram_abi_version(void);
+
+/* ---- 3x3x3 convolution, stride 1, zero padding 1 (nn.Conv3d at parts.py:95,105,133,142,177,185) ----
+ *
+ * The kernels take the filter in a GEMM-friendly layout wt[27][Cin][Cout]
+ * (tap-major, Cout fastest).  dram_conv3d_k3_pack_weights builds it from the
+ * reference's [Cout][Cin][3][3][3] parameter:
+ *   mode 0 (forward):  wt[t][ci][co] = w[co][ci][t]
+ *   mode 1 (backward-data): wt[t][co][ci] = w[co][ci][26-t], i.e. the filter
+ *          of the transposed convolution -- run dram_conv3d_k3_fwd on dy with
+ *          Cin/Cout swapped to obtain dx.
+ */
+int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, int Cin, int mode, void* stream);
+
+/* y[N,Cout,D,H,W] = conv3d(x[N,Cin,D,H,W], w) (+ bias[Cout] when bias != NULL). */
+int dram_conv3d_k3_fwd(const float* x, const float* wt, const float* bias, float* y,
+                       int N, int Cin, int Cout, int D, int H, int W, void* stream);
+
+/* Same, with the input given as the channel concatenation of two tensors that
+ * is never materialised: channels [0,C1) come from x1[N,C1,D,H,W]; channels
+ * [C1,C1+C2) from x2[N,C2,D2,H2,W2] centre-cropped with start offsets
+ * (oz,oy,ox) -- crop_concat_5d of parts.py:37-46 fused into the consumer conv
+ * (parts.py:153-154). */
+int dram_conv3d_k3_fwd_cat(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
+                           int oz, int oy, int ox, const float* wt, const float* bias, float* y,
+                           int N, int Cout, int D, int H, int W, void* stream);
+
+/* General form of the two calls above, also used for backward-data: the INPUT is the (virtual)
+ * concatenation x1[N,C1,D,H,W] ++ crop(x2[N,C2,D2,H2,W2]) (x2 == NULL: x1 only) and the OUTPUT
+ * channels are split the same way over y1[N,Co1,D,H,W] and, when y2 != NULL, the crop window
+ * (yoz,yoy,yox) of y2[N,Co2,yD2,yH2,yW2] (elements of y2 outside the window are not written:
+ * zero them first when the window is smaller than y2).  wt is [27][C1+C2][Co1+Co2]. */
+int dram_conv3d_k3_fwd_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
+                          int oz, int oy, int ox, const float* wt, const float* bias,
+                          float* y1, int Co1, float* y2, int Co2, int yD2, int yH2, int yW2,
+                          int yoz, int yoy, int yox, int N, int D, int H, int W, void* stream);
+
+/* dw[Cout,Cin,3,3,3] = sum over (n,z,y,x) of dy[n,co,z,y,x] * xpad[n,ci,z+dz,y+dy,x+dx].
+ * Deterministic: per-block partial slabs in `ws`, summed in a fixed order. */
+size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int dram_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                         int N, int Cin, int Cout, int D, int H, int W, void* stream);
+
+/* Same with x given as a virtual concatenation (Cin = C1 + C2; size the workspace for that Cin). */
+int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
+                            int oz, int oy, int ox, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                            int N, int Cout, int D, int H, int W, void* stream);
+
+/* dbias[Cout] = sum over (n,z,y,x) of dy (conv_bias=True when norm_method is None, models.py:78). */
+size_t dram_channel_sum_ws_bytes(int N, int C, int64_t S);
+int dram_channel_sum(const float* dy, float* dbias, void* ws, size_t ws_bytes, int N, int C, int64_t S, void* stream);
+
+/* ---- normalisation (+ fused ReLU) (normal_wrapper parts.py:17-35, act_wrapper parts.py:48-54) ----
+ *
+ * Training-mode forward: computes statistics of x (two-level Chan/Welford
+ * combination, fp64 finalise), writes y = act(gamma * (x - mean) * rstd + beta).
+ *   kind = DRAM_NORM_BATCH: one statistic per channel; save_mean/save_rstd have
+ *          C entries; when running_mean != NULL the running statistics are
+ *          updated in place with `momentum` (unbiased variance), as
+ *          nn.BatchNorm3d does.
+ *   kind = DRAM_NORM_GROUP: one statistic per (n, group); save_* have N*G entries.
+ * gamma/beta may be NULL (affine=False).  relu != 0 fuses nn.ReLU.
+ * Also fills rowcoef[2*N*C] = {a,b} with y_pre = a*x + b per row, which the
+ * backward entry point reuses.
+ */
+size_t dram_norm_ws_bytes(int N, int C, int64_t S);
+int dram_norm_fwd_train(const float* x, const float* gamma, const float* beta, float* y,
+                        float* save_mean, float* save_rstd, float* rowcoef,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        int kind, int G, int relu, int N, int C, int64_t S,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* Eval-mode BatchNorm: y = act(gamma * (x - running_mean) / sqrt(running_var + eps) + beta);
+ * fills save_mean/save_rstd/rowcoef like the training entry so backward works. */
+int dram_bn_fwd_eval(const float* x, const float* gamma, const float* beta,
+                     const float* running_mean, const float* running_var, float* y,
+                     float* save_mean, float* save_rstd, float* rowcoef,
+                     float eps, int relu, int N, int C, int64_t S, void* stream);
+
+/* Backward of the above.  dy is the gradient w.r.t. the (activated) output; x is
+ * the saved input; the ReLU mask is recomputed from rowcoef.  Outputs dx (may
+ * alias dy), dgamma[C], dbeta[C] (either may be NULL).  `batch_stats` = 1 when
+ * the forward used the statistics of x itself (training), 0 for eval-mode BN. */
+int dram_norm_bwd(const float* dy, const float* x, const float* gamma,
+                  const float* save_mean, const float* save_rstd, const float* rowcoef,
+                  float* dx, float* dgamma, float* dbeta,
+                  int kind, int G, int relu, int batch_stats, int N, int C, int64_t S,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* Stand-alone activations (act_wrapper parts.py:48-54 when no norm precedes them). */
+int dram_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int dram_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* ---- nn.MaxPool3d(2, 2, 0) (parts.py:191) ----
+ * out[N,C,D/2,H/2,W/2]; idx (uint8, 0..7 = dz*4+dy*2+dx) records the first
+ * maximum in (z,y,x) scan order -- the element ATen routes the gradient to. */
+int dram_maxpool3d_2_fwd(const float* x, float* out, uint8_t* idx, int N, int C, int D, int H, int W, void* stream);
+int dram_maxpool3d_2_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H, int W, void* stream);
+
+/* ---- nn.Upsample(mode='trilinear', align_corners=True) (parts.py:149 scale 2; models.py:146 to input size) ----
+ * Arbitrary (D,H,W) -> (Do,Ho,Wo); source index = dst * (in-1)/(out-1) as ATen computes it.
+ * The backward is the exact adjoint in gather form (deterministic, no atomics). */
+int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, int C, int D, int H, int W,
+                                   int Do, int Ho, int Wo, void* stream);
+int dram_upsample_trilinear_ac_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W,
+                                   int Do, int Ho, int Wo, void* stream);
+
+/* ---- crop_concat_5d (parts.py:37-46) ----
+ * out[N,C1+C2,D,H,W] = cat(t1[N,C1,D,H,W], t2[N,C2,D2,H2,W2][..., oz:oz+D, oy:oy+H, ox:ox+W]). */
+int dram_crop_concat_fwd(const float* t1, const float* t2, float* out, int N, int C1, int C2,
+                         int D, int H, int W, int D2, int H2, int W2, int oz, int oy, int ox, void* stream);
+/* dt1 = dout[:, :C1]; dt2 = 0 outside the crop window, dout[:, C1:] inside.  Either output may be NULL. */
+int dram_crop_concat_bwd(const float* dout, float* dt1, float* dt2, int N, int C1, int C2,
+                         int D, int H, int W, int D2, int H2, int W2, int oz, int oy, int ox, void* stream);
+
+/* ---- 1x1x1 convolution with bias: the regression head top_layer (models.py:109-110, 145) ---- */
+int dram_conv3d_k1_fwd(const float* x, const float* w, const float* bias, float* y,
+                       int N, int Cin, int Cout, int64_t S, void* stream);
+size_t dram_conv3d_k1_bwd_ws_bytes(int N, int Cin, int Cout, int64_t S);
+/* dx[N,Cin,S] (may be NULL), dw[Cout,Cin], dbias[Cout] (may be NULL). */
+int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                       void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S, void* stream);
+
+/* ---- lobe-masked mean: pooling_dense_features (models.py:37-49, default branch) ----
+ * out[n,c] = sum_s x[n,c,s]*m[n,s] / sum_s m[n,s];  msum[n] = sum_s m[n,s] is also returned. */
+size_t dram_masked_mean_ws_bytes(int N, int C, int64_t S);
+int dram_masked_mean_fwd(const float* x, const float* mask, float* out, float* msum,
+                         void* ws, size_t ws_bytes, int N, int C, int64_t S, void* stream);
+/* dx[n,c,s] = dout[n,c] * m[n,s] / msum[n]. */
+int dram_masked_mean_bwd(const float* dout, const float* mask, const float* msum, float* dx,
+                         int N, int C, int64_t S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRAM_HIP_H */

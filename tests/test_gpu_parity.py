@@ -1,0 +1,414 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors generated from the reference.  Stated tolerance (BASELINE.json north_star):
+1e-4 relative (max-abs error over max |reference|, and relative L2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dram_oracle as O
+from oracle.make_golden import SLIM
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(np.asarray(got)).double()
+    ref = ref.detach().double().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(np.asarray(ref)).double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if ref.numel() == 0:
+        return 0.0, 0.0
+    scale = max(ref.abs().max().item(), 1e-30)
+    return (got - ref).abs().max().item() / scale, ((got - ref).norm() / max(ref.norm().item(), 1e-30)).item()
+
+
+def check(got, ref, what, tol=TOL):
+    mx, l2 = rel_err(got, ref)
+    assert mx <= tol and l2 <= tol, f"{what}: max-rel {mx:.3e}, rel-L2 {l2:.3e} > {tol}"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+# ------------------------------------------------------------------ conv 3x3x3
+CONV_CASES = [
+    # N, Cin, Cout, D, H, W, bias
+    (2, 3, 4, 6, 10, 12, False),      # W < 12 -> 8-wide boxes... (12 -> 16-wide)
+    (1, 5, 7, 7, 9, 11, True),        # odd everything, bias
+    (2, 8, 16, 5, 6, 7, False),       # W = 7 -> 8-wide boxes
+    (1, 1, 32, 9, 17, 33, False),     # first layer shape class (Cin = 1), 32-wide boxes
+    (1, 32, 64, 6, 10, 40, False),    # Cout = 64 (two channel tiles), partial x boxes
+    (2, 20, 70, 8, 8, 16, False),     # Cout not a multiple of 64, Cin not a multiple of 4/16
+    (1, 64, 64, 4, 36, 36, False),
+    (1, 130, 40, 3, 5, 20, True),     # Cin > 128
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_k3_fwd_bwd(case):
+    from dram_amd import functional as HF
+    N, Ci, Co, D, H, W, use_bias = case
+    x = torch.randn(N, Ci, D, H, W, generator=g(1))
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g(2)) / (Ci * 27) ** 0.5
+    b = torch.randn(Co, generator=g(3)) if use_bias else None
+    gy = torch.randn(N, Co, D, H, W, generator=g(4))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if use_bias else None
+    yr = O.conv3d(xr, wr, br, 1)
+    yr.backward(gy)
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    bg = dev(b).requires_grad_(True) if use_bias else None
+    y = HF.conv3d_k3(xg, wg, bg)
+    y.backward(dev(gy))
+    check(y, yr, f"conv fwd {case}")
+    check(xg.grad, xr.grad, f"conv dgrad {case}")
+    check(wg.grad, wr.grad, f"conv wgrad {case}")
+    if use_bias:
+        check(bg.grad, br.grad, f"conv dbias {case}")
+
+
+@pytest.mark.parametrize("shape", [((2, 6, 4, 6, 8), (2, 5, 4, 6, 8)),       # same size: identity crop
+                                   ((2, 6, 6, 10, 12), (2, 4, 7, 11, 13)),   # crop offsets (1,1,1) (ceil)
+                                   ((1, 3, 5, 6, 20), (1, 9, 8, 9, 24))])
+def test_conv3d_k3_virtual_concat(shape):
+    """conv(crop_concat_5d(up, skip)) without materialising the concatenation."""
+    from dram_amd import functional as HF
+    s1, s2 = shape
+    up = torch.randn(*s1, generator=g(5))
+    skip = torch.randn(*s2, generator=g(6))
+    Ci, Co = s1[1] + s2[1], 10
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g(7)) / (Ci * 27) ** 0.5
+    gy = torch.randn(s1[0], Co, *s1[2:], generator=g(8))
+    ur, sr, wr = up.clone().requires_grad_(True), skip.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = O.conv3d(O.crop_concat_5d(ur, sr), wr, None, 1)
+    yr.backward(gy)
+    ug, sg, wg = dev(up).requires_grad_(True), dev(skip).requires_grad_(True), dev(w).requires_grad_(True)
+    y = HF.conv3d_k3(ug, wg, None, skip=sg)
+    y.backward(dev(gy))
+    check(y, yr, "cat conv fwd")
+    check(ug.grad, ur.grad, "cat conv d(up)")
+    check(sg.grad, sr.grad, "cat conv d(skip)")
+    check(wg.grad, wr.grad, "cat conv wgrad")
+    # and the stand-alone crop_concat_5d kernel
+    out = HF.crop_concat(dev(up), dev(skip))
+    assert torch.equal(out.cpu(), O.crop_concat_5d(up, skip))
+
+
+def test_conv3d_k3_linearity_and_shift_large():
+    """Size-independent properties at a layer-sized shape (config-2 class: 64->64 channels):
+    linearity in x and agreement with the oracle on an interior sub-volume."""
+    from dram_amd import functional as HF
+    N, C, S = 2, 64, 64
+    x1 = torch.randn(N, C, S, S, S, generator=g(9), device="cpu")
+    x2 = torch.randn(N, C, S, S, S, generator=g(10), device="cpu")
+    w = torch.randn(C, C, 3, 3, 3, generator=g(11)) / (C * 27) ** 0.5
+    xa, xb, wg = dev(x1), dev(x2), dev(w)
+    with torch.no_grad():
+        ya, yb = HF.conv3d_k3(xa, wg), HF.conv3d_k3(xb, wg)
+        yab = HF.conv3d_k3(2.0 * xa - 0.5 * xb, wg)
+    check(yab, 2.0 * ya - 0.5 * yb, "conv linearity", tol=2e-5)
+    # oracle on a sub-volume: output [8:24]^3 depends on input [7:25]^3 only
+    sub = x1[:, :, 7:25, 7:25, 7:25].contiguous()
+    ref = O.conv3d(sub, w, None, 0)    # valid conv of the haloed crop
+    check(ya[:, :, 8:24, 8:24, 8:24], ref, "conv fwd interior vs oracle")
+    # border voxels see zero padding
+    ref0 = O.conv3d(x1[:1, :, :10, :10, :10].contiguous(), w, None, 1)[:, :, :8, :8, :8]
+    check(ya[:1, :, :8, :8, :8], ref0, "conv fwd corner vs oracle")
+
+
+# ------------------------------------------------------------------ norms
+NORM_SHAPES = [(2, 6, 6, 10, 12), (3, 4, 7, 9, 11), (2, 8, 24, 24, 24)]   # 693-voxel rows exercise the scalar path
+
+
+@pytest.mark.parametrize("shape", NORM_SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("affine", [True, False])
+def test_batchnorm_train_eval(shape, relu, affine):
+    from dram_amd.modules import HipBatchNorm3d
+    C = shape[1]
+    x = torch.randn(*shape, generator=g(12)) * 1.7 + 0.6
+    gy = torch.randn(*shape, generator=g(13))
+    ref = torch.nn.BatchNorm3d(C, affine=affine)
+    mod = HipBatchNorm3d(C, affine=affine)
+    if affine:
+        ref.weight.data = torch.rand(C, generator=g(14)) + 0.5
+        ref.bias.data = torch.randn(C, generator=g(15)) * 0.3
+        mod.load_state_dict(ref.state_dict())
+    mod = mod.to(DEV)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gy)
+    xg = dev(x).requires_grad_(True)
+    y = mod(xg, relu=relu)
+    y.backward(dev(gy))
+    check(y, yr, "bn train fwd")
+    check(xg.grad, xr.grad, "bn train dx")
+    if affine:
+        check(mod.weight.grad, ref.weight.grad, "bn dgamma")
+        check(mod.bias.grad, ref.bias.grad, "bn dbeta")
+    check(mod.running_mean, ref.running_mean, "bn running_mean")
+    check(mod.running_var, ref.running_var, "bn running_var")
+    assert int(mod.num_batches_tracked) == 1
+    # eval mode with the updated buffers, including backward through running statistics
+    ref.eval(), mod.eval()
+    xr2, xg2 = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+    yr2 = ref(xr2)
+    yr2 = F.relu(yr2) if relu else yr2
+    yr2.backward(gy)
+    y2 = mod(xg2, relu=relu)
+    y2.backward(dev(gy))
+    check(y2, yr2, "bn eval fwd")
+    check(xg2.grad, xr2.grad, "bn eval dx")
+
+
+@pytest.mark.parametrize("shape", NORM_SHAPES)
+@pytest.mark.parametrize("groups", ["one", "all", "two"])
+@pytest.mark.parametrize("relu", [False, True])
+def test_groupnorm(shape, groups, relu):
+    from dram_amd.modules import HipGroupNorm
+    C = shape[1]
+    G = {"one": 1, "all": C, "two": 2}[groups]
+    x = torch.randn(*shape, generator=g(16)) * 2.0 - 0.4
+    gy = torch.randn(*shape, generator=g(17))
+    ref = torch.nn.GroupNorm(G, C)
+    ref.weight.data = torch.rand(C, generator=g(18)) + 0.5
+    ref.bias.data = torch.randn(C, generator=g(19)) * 0.3
+    mod = HipGroupNorm(G, C)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(DEV)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gy)
+    xg = dev(x).requires_grad_(True)
+    y = mod(xg, relu=relu)
+    y.backward(dev(gy))
+    check(y, yr, "gn fwd")
+    check(xg.grad, xr.grad, "gn dx")
+    check(mod.weight.grad, ref.weight.grad, "gn dgamma")
+    check(mod.bias.grad, ref.bias.grad, "gn dbeta")
+
+
+def test_batchnorm_statistics_with_large_mean():
+    """|mean| >> std: a naive E[x^2]-E[x]^2 in fp32 fails this; the Chan combination must not."""
+    from dram_amd.modules import HipBatchNorm3d
+    x = torch.randn(4, 3, 40, 40, 40, generator=g(20)) * 0.05 + torch.tensor([100.0, -50.0, 10.0]).view(1, 3, 1, 1, 1)
+    mod = HipBatchNorm3d(3).to(DEV)
+    y = mod(dev(x))
+    xd = x.double()
+    mean = xd.mean(dim=(0, 2, 3, 4), keepdim=True)
+    var = xd.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+    ref = (xd - mean) / torch.sqrt(var + 1e-5)
+    check(y, ref.float(), "bn large-mean", tol=2e-3)   # the input itself only carries ~1e-7*100/0.05 = 2e-4 relative
+    check(mod.running_var, (0.9 + 0.1 * xd.var(dim=(0, 2, 3, 4), unbiased=True)).float(), "bn large-mean running_var", tol=1e-3)
+
+
+# ------------------------------------------------------------------ pool / resize / head
+@pytest.mark.parametrize("shape", [(2, 3, 6, 10, 12), (1, 4, 7, 9, 11), (2, 2, 16, 16, 32)])
+def test_maxpool_with_ties(shape):
+    from dram_amd import functional as HF
+    x = torch.relu(torch.randn(*shape, generator=g(21)))     # ~50 % zeros: ties in most windows
+    x[0, 0, :2, :2, :2] = 3.0                                 # an all-equal window
+    xr = x.clone().requires_grad_(True)
+    yr = O.max_pool3d_2(xr)
+    gy = torch.randn(yr.shape, generator=g(22))
+    yr.backward(gy)
+    xg = dev(x).requires_grad_(True)
+    y = HF.max_pool3d_2(xg)
+    y.backward(dev(gy))
+    assert torch.equal(y.cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)                # same tie-breaking as ATen: bit-exact routing
+
+
+@pytest.mark.parametrize("case", [((2, 3, 3, 5, 6), None, 2), ((1, 2, 4, 4, 4), None, (2, 2, 2)),
+                                  ((1, 2, 5, 6, 7), (9, 13, 8), None), ((2, 1, 16, 16, 16), (21, 18, 20), None),
+                                  ((1, 2, 1, 4, 5), (3, 8, 10), None), ((1, 1, 6, 6, 6), (6, 6, 6), None),
+                                  ((1, 2, 8, 7, 9), (4, 5, 3), None)])
+def test_trilinear_align_corners(case):
+    from dram_amd import functional as HF
+    shape, size, sf = case
+    x = torch.randn(*shape, generator=g(23))
+    xr = x.clone().requires_grad_(True)
+    yr = O.upsample_trilinear_ac(xr, scale_factor=sf, size=size)
+    gy = torch.randn(yr.shape, generator=g(24))
+    yr.backward(gy)
+    xg = dev(x).requires_grad_(True)
+    y = HF.upsample_trilinear_ac(xg, size=size, scale_factor=sf)
+    y.backward(dev(gy))
+    check(y, yr, f"trilinear fwd {case}", tol=1e-5)
+    check(xg.grad, xr.grad, f"trilinear bwd {case}", tol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 1, (6, 10, 12)), (1, 8, 3, (7, 9, 11)), (2, 5, 11, (4, 4, 8))])
+def test_conv1x1_head(case):
+    from dram_amd import functional as HF
+    N, Ci, Co, sp = case
+    x = torch.randn(N, Ci, *sp, generator=g(25))
+    w = torch.randn(Co, Ci, 1, 1, 1, generator=g(26))
+    b = torch.randn(Co, generator=g(27))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.conv3d(xr, wr, br, 0)
+    gy = torch.randn(yr.shape, generator=g(28))
+    yr.backward(gy)
+    xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = HF.conv3d_k1(xg, wg, bg)
+    y.backward(dev(gy))
+    check(y, yr, "conv1x1 fwd")
+    check(xg.grad, xr.grad, "conv1x1 dx")
+    check(wg.grad, wr.grad, "conv1x1 dw")
+    check(bg.grad, br.grad, "conv1x1 db")
+
+
+def test_masked_mean_pooling():
+    import models
+    x = torch.randn(3, 4, 6, 7, 9, generator=g(29))
+    m = (torch.rand(3, 1, 6, 7, 9, generator=g(30)) > 0.4).float()
+    xr = x.clone().requires_grad_(True)
+    yr = O.pooling_dense_features(xr, m)
+    gy = torch.randn(yr.shape, generator=g(31))
+    yr.backward(gy)
+    xg = dev(x).requires_grad_(True)
+    y = models.pooling_dense_features(xg, dev(m))
+    y.backward(dev(gy))
+    check(y, yr, "masked mean fwd")
+    check(xg.grad, xr.grad, "masked mean bwd")
+    check(models.pooling_dense_features(dev(x), dev(m), "global_avg"), O.pooling_dense_features(x, m, "global_avg"), "global avg")
+
+
+# ------------------------------------------------------------------ blocks vs the reference's own outputs
+def _sub(z, prefix):
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def _load_block(block, z, tag):
+    sd = {k: torch.from_numpy(v) for k, v in _sub(z, tag + "sd/").items()}
+    block.load_state_dict(sd)
+    return block.to(DEV)
+
+
+@pytest.mark.parametrize("norm", ["bn", "ln", "in", "bnt", "bntna", "lnna", "None"])
+@pytest.mark.parametrize("shape", ["even", "odd"])
+def test_convpool_block_golden(golden_dir, norm, shape):
+    import parts
+    z = np.load(os.path.join(golden_dir, "blocks.npz"))
+    tag = f"convpool/{norm}/{shape}/"
+    nm = None if norm == "None" else norm
+    blk = parts.ConvPoolBlock5d([3, 4], [4, 6], 0, (3, 3), nm is None, (1, 1), 2, 2, 0, dropout=0.0,
+                                norm_method=nm, act_method="relu")
+    blk = _load_block(blk, z, tag)
+    x = dev(torch.from_numpy(z[tag + "in0"])).requires_grad_(True)
+    y, pooled = blk(x)
+    check(y, z[tag + "out/y"], tag + "y")
+    check(pooled, z[tag + "out/pooled"], tag + "pooled")
+    ((y * dev(torch.from_numpy(z[tag + "gout/y"]))).sum() + (pooled * dev(torch.from_numpy(z[tag + "gout/pooled"]))).sum()).backward()
+    check(x.grad, z[tag + "gin0"], tag + "gin")
+    for k, p in blk.named_parameters():
+        check(p.grad, z[tag + "gparam/" + k], tag + "gparam/" + k)
+    for k, v in _sub(z, tag + "sd_after/").items():
+        check(blk.state_dict()[k].float(), v.astype(np.float32), tag + "sd_after/" + k)
+    blk.eval()
+    with torch.no_grad():
+        ye, pe = blk(x.detach())
+    check(ye, z[tag + "eval/y"], tag + "eval y")
+    check(pe, z[tag + "eval/pooled"], tag + "eval pooled")
+
+
+@pytest.mark.parametrize("kind", ["bn", "ln", "lite"])
+def test_conv_block_golden(golden_dir, kind):
+    import parts
+    z = np.load(os.path.join(golden_dir, "blocks.npz"))
+    tag = f"conv/{kind}/"
+    if kind == "lite":
+        blk = parts.ConvBlock5d([5, 8], [8, 7], 0, 3, True, 1, 0.0, lite=True)
+    else:
+        blk = parts.ConvBlock5d([5, 8], [8, 7], 0, 3, False, 1, 0.0, norm_method=kind)
+    blk = _load_block(blk, z, tag)
+    x = dev(torch.from_numpy(z[tag + "in0"])).requires_grad_(True)
+    y = blk(x)
+    check(y, z[tag + "out/y"], tag + "y")
+    (y * dev(torch.from_numpy(z[tag + "gout/y"]))).sum().backward()
+    check(x.grad, z[tag + "gin0"], tag + "gin")
+    for k, p in blk.named_parameters():
+        check(p.grad, z[tag + "gparam/" + k], tag + "gparam/" + k)
+
+
+@pytest.mark.parametrize("norm", ["bn", "in"])
+def test_upconv_block_golden(golden_dir, norm):
+    import parts
+    z = np.load(os.path.join(golden_dir, "blocks.npz"))
+    tag = f"upconv/{norm}/"
+    blk = parts.UpsampleConvBlock5d([10, 5], [5, 4], 0, (2, 2, 2), (3, 3), False, (1, 1), dropout=0.0, norm_method=norm)
+    blk = _load_block(blk, z, tag)
+    lo = dev(torch.from_numpy(z[tag + "in0"])).requires_grad_(True)
+    cat = dev(torch.from_numpy(z[tag + "in1"])).requires_grad_(True)
+    y = blk(lo, cat)
+    check(y, z[tag + "out/y"], tag + "y")
+    (y * dev(torch.from_numpy(z[tag + "gout/y"]))).sum().backward()
+    check(lo.grad, z[tag + "gin0"], tag + "gin0")
+    check(cat.grad, z[tag + "gin1"], tag + "gin1")
+    for k, p in blk.named_parameters():
+        check(p.grad, z[tag + "gparam/" + k], tag + "gparam/" + k)
+
+
+# ------------------------------------------------------------------ whole model vs the reference's own outputs
+@pytest.mark.parametrize("tag,norm", [("slim_bn", "bn"), ("slim_ln", "ln"), ("slim_in_odd", "in")])
+def test_dc3d_slim_golden(golden_dir, tag, norm):
+    import models
+    z = np.load(os.path.join(golden_dir, "dc3d_slim.npz"))
+    model = models.DC3D(**SLIM, norm_method=norm)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in _sub(z, tag + "/sd/").items()})
+    model = model.to(DEV)
+    x = dev(torch.from_numpy(z[tag + "/x"]))
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)[0]
+    check(ev, z[tag + "/eval_out"], tag + " eval")
+    model.train()
+    d0, d1 = model(x, None)
+    assert d0 is d1
+    check(d0, z[tag + "/train_out"], tag + " train")
+    (d0 * dev(torch.from_numpy(z[tag + "/gout"]))).sum().backward()
+    grads = dict(model.named_parameters())
+    for k, gref in _sub(z, tag + "/grad/").items():
+        check(grads[k].grad, gref, f"{tag} grad {k}", tol=5e-4)
+    for k, v in _sub(z, tag + "/sd_after/").items():
+        check(model.state_dict()[k].double(), v.astype(np.float64), f"{tag} buffer {k}")
+
+
+def test_dc3d_full_golden(golden_dir):
+    """st_dram_ref.MODEL (16.3 M parameters): weights re-created from seed 0 (identical to the
+    reference's, checked on CPU in test_host_cpu.py), output and gradients vs the reference run."""
+    import models
+    z = np.load(os.path.join(golden_dir, "dc3d_full.npz"))
+    torch.manual_seed(0)
+    model = models.DC3D(**O.ST_DRAM_REF_MODEL)
+    model.init(models.HeNorm(mode="fan_in"))
+    model = model.to(DEV)
+    x = dev(torch.from_numpy(z["full_bn/x"]))
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)[0]
+    check(ev, z["full_bn/eval_out"], "full eval")
+    model.train()
+    d0, _ = model(x)
+    check(d0, z["full_bn/train_out"], "full train")
+    (d0 * dev(torch.from_numpy(z["full_bn/gout"]))).sum().backward()
+    grads = dict(model.named_parameters())
+    for k, gref in _sub(z, "full_bn/grad/").items():
+        check(grads[k].grad, gref, f"full grad {k}", tol=5e-4)
+    for k, v in _sub(z, "full_bn/gradnorm/").items():
+        got = grads[k].grad.double().norm().item()
+        assert abs(got - float(v)) <= 1e-3 * max(float(v), 1e-12), (k, got, float(v))
+    for k, v in _sub(z, "full_bn/sd_after/").items():
+        check(model.state_dict()[k].double(), v.astype(np.float64), f"full buffer {k}")
+    assert int(model.state_dict()["ds_modules.1.conv_blocks.0.1.num_batches_tracked"]) == 2
