@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the DRAM DC3D hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one optimisation step (forward + loss + backward + gradient all-reduce + Adam) of the
+reference's benchmark model `st_dram_ref.MODEL` (DC3D, BatchNorm, fp32, activation checkpointing as
+shipped) on this rank's batch of synthetic lobe chunks: 64 chunks of 1x128^3 per GPU (the shape
+BASELINE.json's metric names), processed as gradient-accumulated micro-batches because 64x128^3 of
+saved activations does not fit 288 GB un-fused.  Inputs are resident in HBM before the
+timed region.  Weak scaling: the per-GPU batch is fixed.
+
+Rank 0 prints one JSON line: metric/value (whole-job voxels/s), roofline of the dominant kernel
+(3x3x3 conv implicit GEMM on fp32 MFMA, timed live with HIP events), cpu_baseline (the oracle's
+torch-CPU DC3D timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "bodyct-dram_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunks", type=int, default=64, help="chunks per GPU per step (metric: 64)")
+    ap.add_argument("--size", type=int, default=128, help="chunk edge (metric: 128)")
+    ap.add_argument("--micro", type=int, default=16, help="micro-batch (chunks) for gradient accumulation")
+    ap.add_argument("--norm", default="bn", help="norm_method of the model (reference default: bn)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
+    return ap.parse_args()
+
+
+def ensure_built():
+    if not os.path.exists(os.path.join(PKG, "libdram_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def cpu_baseline(budget_s):
+    """The oracle's torch-CPU DC3D (same config, same step shape at reduced batch) on the host cores."""
+    import torch
+    from oracle import dram_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = O.ST_DRAM_REF_MODEL
+    params, buffers = O.init_params(cfg, "bn", seed=0)
+    for p in params.values():
+        p.requires_grad_(True)
+    n, s = 1, 64
+    x = torch.rand(n, 1, s, s, s, generator=torch.Generator().manual_seed(1))
+    gout = torch.randn(n, 1, s, s, s, generator=torch.Generator().manual_seed(2))
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        out = O.dc3d_forward(cfg, params, buffers, x, training=True, norm_method="bn")
+        (out * gout).sum().backward()
+
+    t0 = time.perf_counter()
+    step()                                    # warm-up
+    first = time.perf_counter() - t0
+    times = []
+    while len(times) < 3 or (sum(times) + first < budget_s and len(times) < 10):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+        if sum(times) + first > budget_s and len(times) >= 1:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n * s ** 3 / med, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd, {n}x1x{s}^3, median of {len(times)} reps "
+                      f"after 1 warm-up, {threads} threads"}
+
+
+def main():
+    args = parse()
+    ensure_built()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import models
+    from dram_amd import functional as HF
+    from dram_amd.train_step import DataParallelTrainer, synthetic_batch
+    from oracle.dram_oracle import ST_DRAM_REF_MODEL
+
+    torch.manual_seed(0)                                   # same initial replica on every rank
+    model = models.DC3D(**ST_DRAM_REF_MODEL, norm_method=args.norm)
+    model.init(models.HeNorm(mode="fan_in"))
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = DataParallelTrainer(model, opt)
+    batch = synthetic_batch(args.chunks, args.size, 100 + rank, dev)   # resident in HBM before timing
+    vox_per_rank = args.chunks * args.size ** 3
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch, args.micro)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(batch, args.micro)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = world * vox_per_rank * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events around every conv launch of one more step
+    roofline = None
+    kernels = {}
+    if rank == 0 and not args.no_kernel_timer:
+        HF.TIMER = HF.KernelTimer()
+        trainer.step(batch, args.micro)
+        summ = HF.TIMER.summary()
+        HF.TIMER = None
+        for k, d in summ.items():
+            kernels[k] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"], "total_ms": d["ms"],
+                          "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
+        if summ:
+            dom = max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                        "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
+                        "algorithmic_flops_per_launch": d["flops"] / d["launches"], "traffic": None}
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
+            if os.path.exists(pmc):
+                try:
+                    roofline["traffic"] = json.load(open(pmc)).get(dom)
+                except Exception:
+                    pass
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        flops_per_voxel = 5415936.0     # fwd+bwd algorithmic FLOPs per input voxel
+        line = {
+            "metric": "voxels/sec fwd+bwd (DC3D train step) on 64x128^3 CT chunks per GPU",
+            "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DC3D st_dram_ref (norm={args.norm}, checkpoint_layers as shipped) "
+                                   f"fwd+loss+bwd+Adam, {args.chunks}x1x{args.size}^3 chunks per GPU, "
+                                   f"micro-batch {args.micro}, fp32",
+                       "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,
+                       "parallelism": f"dp{world}"},
+            "per_gpu_voxels_per_s": value / world,
+            "network_frac_of_fp32_peak": value / world * flops_per_voxel / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

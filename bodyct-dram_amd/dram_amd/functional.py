@@ -21,6 +21,51 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches on the stream they run on
+    (used by bench.py for the roofline line).  Disabled (None) by default: zero overhead."""
+
+    def __init__(self):
+        self.records = []   # (key, flops, bytes, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+TIMER = None   # set to a KernelTimer() to record
+
+
+def _timed_call(key, flops, nbytes, name, *args):
+    if TIMER is None:
+        call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(name, *args)
+    e1.record()
+    TIMER.records.append((key, flops, nbytes, e0, e1))
+
+
+def conv_fwd_kernel_name(W, Cout):
+    """Name of the conv3d_k3_fwd_kernel instantiation the library picks (csrc/conv3d_k3.hip
+    conv_fwd_dispatch / launch_fwd), as rocprofv3 prints it."""
+    box = "32, 4, 2" if W >= 24 else ("16, 4, 4" if W >= 12 else "8, 8, 4")
+    return f"conv3d_k3_fwd_kernel<{box}, {1 if Cout <= 32 else 2}>"
+
+
+def conv_wgrad_kernel_name(W):
+    box = "32, 2, 2" if W >= 24 else ("16, 4, 2" if W >= 12 else "8, 4, 4")
+    return f"conv3d_k3_wgrad_kernel<{box}>"
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -83,8 +128,10 @@ class Conv3dK3Fn(Function):
             bias = _chk(bias, "conv3d bias", 1)
         wt = _pack(w, 0)
         y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x1.device)
-        call("dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
-             _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
+        vox = N * D * H * W
+        _timed_call(conv_fwd_kernel_name(W, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                    "dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
+                    _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
         ctx.save_for_backward(x1, x2, w)
         ctx.has_bias = bias is not None
         ctx.geom = (C2, D2, H2, W2, oz, oy, ox)
@@ -108,8 +155,10 @@ class Conv3dK3Fn(Function):
             if x2 is not None:
                 full = (D2, H2, W2) == (D, H, W)
                 dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
-            call("dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
-                 _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
+            vox = N * D * H * W
+            _timed_call(conv_fwd_kernel_name(W, Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                        "dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
+                        _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
             if not need1:
                 dx1 = None
             if not need2:
@@ -118,8 +167,10 @@ class Conv3dK3Fn(Function):
             dw = torch.empty_like(w)
             nbytes = _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)
             ws = _ws(nbytes, dy.device)
-            call("dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
-                 _p(ws), ws.numel(), N, Co, D, H, W, st)
+            vox = N * D * H * W
+            _timed_call(conv_wgrad_kernel_name(W), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                        "dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
+                        _p(ws), ws.numel(), N, Co, D, H, W, st)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             S = D * H * W
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)

@@ -1,0 +1,186 @@
+"""Device-resident restatement of the reference's training step around DC3D
+(`LesionSegChunkTrain.train`, dram/job_runner.py:649-681, with
+`IntRegRefineLoss`, dram/metrics.py:311-373) plus the pure data-parallel wrapper that the
+reference does not have: one process per GPU, gradients averaged with an RCCL
+all-reduce over xGMI.
+
+The loss math is a handful of element-wise passes over [N,1,D,H,W] tensors (<0.01 % of the
+step's FLOPs); it is written with torch ops on the device and -- unlike the reference, which
+round-trips every sample through numpy (metrics.py:338-352) -- never synchronises with the
+host.  The regression targets depend only on the data (lesion ratio, CT severity score), so they
+are computed when the batch is built, as the reference's data loader side would.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+# IntRegLoss.ctss_ratio_map (metrics.py:76-83)
+CTSS_RATIO_MAP = {0: (0.0, 0.001), 1: (0.001, 0.01), 2: (0.01, 0.05),
+                  3: (0.05, 0.35), 4: (0.35, 0.5), 5: (0.5, 1.00001)}
+
+
+def regression_targets(ctsses, ratio_upper_bound, band_width):
+    """IntRegLoss.get_labels (metrics.py:122-138): per-sample [lower, upper] band."""
+    out = []
+    for ctss, lp in zip(ctsses, ratio_upper_bound):
+        lp = float(lp)
+        lb, ub = max(0.0, lp - band_width), min(1.0, lp + band_width)
+        c_lb, c_ub = CTSS_RATIO_MAP[int(float(ctss))]
+        band = (max(c_lb, lb), min(c_ub, ub))
+        if band[1] < band[0]:
+            if ub <= c_lb:
+                band = (lb, ub)
+            elif lb >= c_ub:
+                band = (c_lb, c_ub)
+            else:
+                raise RuntimeError("cannot reach here!")
+        out.append(band)
+    return torch.tensor(out, dtype=torch.float32)
+
+
+class Batch:
+    """One per-rank batch of lobe chunks, already in the post-transform layout the reference's
+    train() feeds the model (job_runner.py:658-660): [N,1,D,H,W] float tensors on the device."""
+
+    def __init__(self, images, lobes, lesions, ctss, freq_map, band_width=1e-2):
+        self.images, self.lobes, self.lesions = images, lobes, lesions
+        self.ctss = [float(c) for c in ctss]
+        B = images.shape[0]
+        ratio_ub = (lesions * lobes).view(B, -1).sum(-1) / lobes.view(B, -1).sum(-1)
+        self.targets = regression_targets(self.ctss, ratio_ub.cpu(), band_width).to(images.device)
+        wf = torch.tensor([freq_map[int(c)] for c in self.ctss], dtype=torch.float32)
+        self.weight = torch.clamp(wf, 0.2, 0.8).to(images.device)           # metrics.py:172-174
+        self.keep = torch.tensor([0.0 if c < 1e-7 else 1.0 for c in self.ctss],
+                                 dtype=torch.float32).view(-1, 1, 1, 1, 1).to(images.device)   # metrics.py:326-327
+
+    def micro(self, lo, hi):
+        b = object.__new__(Batch)
+        b.images, b.lobes, b.lesions = self.images[lo:hi], self.lobes[lo:hi], self.lesions[lo:hi]
+        b.ctss, b.targets, b.weight, b.keep = self.ctss[lo:hi], self.targets[lo:hi], self.weight[lo:hi], self.keep[lo:hi]
+        return b
+
+    def __len__(self):
+        return self.images.shape[0]
+
+
+def synthetic_batch(n, size, seed, device, freq_map=None):
+    """images U[0,1) zeroed outside a centred ellipsoid lobe mask
+    (semi-axes 0.45*S), lesions = (image > 0.7) & lobe, ctss = n mod 6, frequency map 1/6."""
+    D, H, W = (size,) * 3 if isinstance(size, int) else size
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    zz = (torch.arange(D, dtype=torch.float32) - (D - 1) / 2).view(D, 1, 1) / (0.45 * D)
+    yy = (torch.arange(H, dtype=torch.float32) - (H - 1) / 2).view(1, H, 1) / (0.45 * H)
+    xx = (torch.arange(W, dtype=torch.float32) - (W - 1) / 2).view(1, 1, W) / (0.45 * W)
+    lobe = ((zz ** 2 + yy ** 2 + xx ** 2) < 1.0).float().to(device)
+    images = torch.empty((n, 1, D, H, W), dtype=torch.float32, device=device)
+    for i in range(n):   # generate on the host one chunk at a time (bounded host memory)
+        images[i, 0] = torch.rand((D, H, W), generator=g).to(device) * lobe
+    lobes = lobe.view(1, 1, D, H, W).expand(n, 1, D, H, W).contiguous()
+    lesions = ((images > 0.7) & (lobes > 0)).float()
+    ctss = [float(i % 6) for i in range(n)]
+    return Batch(images, lobes, lesions, ctss, freq_map or {k: 1.0 / 6 for k in range(6)})
+
+
+class DeviceIntRegRefineLoss:
+    """IntRegRefineLoss.__call__ (metrics.py:360-373) given the model output `dense` (DC3D returns
+    the same tensor as dense_outs and refined_dense_outs).  Returns (reg_loss, seg_loss)."""
+
+    def __init__(self, band_width=1e-2, smoothing=0.1):
+        self.band_width, self.smoothing, self.eps = band_width, smoothing, 1e-7
+
+    def __call__(self, dense, batch):
+        p = torch.sigmoid(dense)
+        B = p.shape[0]
+        lobes = batch.lobes
+        inside = (lobes > 0).to(p.dtype)
+        # compute_reg_loss_with_probs (metrics.py:158-177): hinge on the lobe-mean probability
+        pred_ratio = (p * inside).view(B, -1).sum(-1) / inside.view(B, -1).sum(-1)
+        lo, hi = batch.targets[:, 0], batch.targets[:, 1]
+        K = (0.5 * (hi - lo)) ** 2
+        reg = torch.clamp((pred_ratio - (hi + lo) / 2.0) ** 2 - K, min=0.0) / batch.weight
+        reg_loss = reg.sum()
+        # compute_seg_loss (metrics.py:331-358): pseudo label, then BootBinCrossEntropy (metrics.py:17-51)
+        with torch.no_grad():
+            t = ((p > 0.5) & (lobes != 0) & (batch.lesions > 0)).to(p.dtype) * batch.keep
+        outside = 1.0 - inside
+        n_out = outside.sum()
+        # outside the lobe t == 0: pt = 1 - p
+        bceo = -(torch.log((1.0 - p).clamp(self.eps, 1.0 - self.eps)) * outside).sum() / n_out
+        n_in = inside.sum()
+        alpha = (1.0 - (t * inside).sum() / n_in).clamp(0.25, 0.75)
+        pt = (p * t + (1.0 - p) * (1.0 - t)).clamp(self.eps, 1.0 - self.eps)
+        w = (alpha * t + (1.0 - alpha) * (1.0 - t)) * inside
+        bce = -(torch.log(pt) * w).sum() / w.sum()
+        ph = torch.maximum(p, 1.0 - p).clamp(self.eps, 1.0 - self.eps)   # p if p > 0.5 else 1 - p
+        boot = -(torch.log(ph) * inside).sum() / n_in
+        seg_loss = bceo + (1.0 - self.smoothing) * bce + self.smoothing * boot
+        return reg_loss, seg_loss
+
+
+class DataParallelTrainer:
+    """One optimisation step of DC3D on this rank's chunks, optionally as micro-batches with
+    gradient accumulation, and -- when torch.distributed is initialised -- an all-reduce (average)
+    of the gradients in a few large flat buckets before the optimiser step.
+
+    xGMI is point-to-point (7 links/GPU): the 65 MB of fp32 gradients take < 1 ms as a ring
+    all-reduce, against a multi-second step, so the buckets are reduced right after the last
+    backward; per-rank BatchNorm statistics (the reference's default "bn") need no exchange."""
+
+    def __init__(self, model, optimizer, loss_fn=None, loss_factors=(2.0, 1.0), bucket_mb=32):
+        self.model, self.opt = model, optimizer
+        self.loss_fn = loss_fn or DeviceIntRegRefineLoss()
+        self.loss_factors = loss_factors           # LOSS_FACTORS[:2] of st_dram_ref.py:42
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.buckets = self._make_buckets(bucket_mb * (1 << 20))
+
+    def _make_buckets(self, cap_bytes):
+        buckets, cur, size = [], [], 0
+        for p in reversed(self.params):            # reverse: roughly the order gradients become ready
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= cap_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            buckets.append(cur)
+        return buckets
+
+    def allreduce_gradients(self):
+        if self.world == 1:
+            return
+        works = []
+        for bucket in self.buckets:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+        for work, flat, bucket in works:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+
+    def step(self, batch, micro_batch=None):
+        """Returns the (detached, device) loss components summed over the rank's batch."""
+        n = len(batch)
+        mb = n if not micro_batch else min(micro_batch, n)
+        self.opt.zero_grad(set_to_none=True)
+        tot_reg = tot_seg = None
+        for lo in range(0, n, mb):
+            b = batch.micro(lo, min(n, lo + mb))
+            dense, _ = self.model(b.images, b.lobes)
+            reg, seg = self.loss_fn(dense, b)
+            # seg_loss is a per-micro-batch mean: weight it by its share of the rank batch
+            loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * (len(b) / n)
+            loss.backward()
+            tot_reg = reg.detach() if tot_reg is None else tot_reg + reg.detach()
+            tot_seg = seg.detach() * (len(b) / n) if tot_seg is None else tot_seg + seg.detach() * (len(b) / n)
+        self.allreduce_gradients()
+        self.opt.step()
+        return tot_reg, tot_seg
