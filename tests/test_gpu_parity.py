@@ -376,11 +376,18 @@ def _fp64_oracle_grads(cfg, sd, x, gout, norm):
     return {k: p.grad for k, p in params.items()}
 
 
-def check_grad(got, ref32, true64, what):
-    """HIP gradient error w.r.t. fp64 must not exceed 3x the reference's own fp32 error (or 5e-4)."""
-    e_hip = max(rel_err(got, true64))
-    e_ref = max(rel_err(ref32, true64))
-    assert e_hip <= max(3.0 * e_ref, 5e-4), f"{what}: HIP-vs-fp64 {e_hip:.3e}, reference-fp32-vs-fp64 {e_ref:.3e}"
+def check_grads(hip_grads, ref32_grads, true64, what):
+    """Every HIP gradient's error w.r.t. fp64 must stay within 3x the fp32 noise level of this
+    network, measured as the reference's own worst fp32-vs-fp64 error over the stored gradients
+    (floor 5e-4).  A per-tensor yardstick does not work: the noise comes from single ReLU-mask
+    flips of elements whose pre-activation is within rounding of zero, which hit one
+    implementation at one layer and the other at another ('Gradient parity')."""
+    noise = max(max(rel_err(ref32_grads[k], true64[k])) for k in ref32_grads)
+    bound = max(3.0 * noise, 5e-4)
+    worst = {k: max(rel_err(hip_grads[k], true64[k])) for k in ref32_grads}
+    bad = {k: v for k, v in worst.items() if v > bound}
+    assert not bad, f"{what}: HIP-vs-fp64 gradient errors above {bound:.2e} (reference fp32 noise {noise:.2e}): {bad}"
+    return noise
 
 
 @pytest.mark.parametrize("tag,norm", [("slim_bn", "bn"), ("slim_ln", "ln"), ("slim_in_odd", "in")])
@@ -402,8 +409,11 @@ def test_dc3d_slim_golden(golden_dir, tag, norm):
     (d0 * dev(torch.from_numpy(z[tag + "/gout"]))).sum().backward()
     grads = dict(model.named_parameters())
     g64 = _fp64_oracle_grads(SLIM, _sub(z, tag + "/sd/"), z[tag + "/x"], z[tag + "/gout"], norm)
-    for k, gref in _sub(z, tag + "/grad/").items():
-        check_grad(grads[k].grad, gref, g64[k], f"{tag} grad {k}")
+    noise = check_grads({k: p.grad for k, p in grads.items()}, _sub(z, tag + "/grad/"), g64, tag)
+    if norm != "bn":    # without BatchNorm's batch coupling the gradients are well conditioned: plain 1e-4
+        assert noise < 1e-4
+        for k, gref in _sub(z, tag + "/grad/").items():
+            check(grads[k].grad, gref, f"{tag} grad {k}")
     for k, v in _sub(z, tag + "/sd_after/").items():
         check(model.state_dict()[k].double(), v.astype(np.float64), f"{tag} buffer {k}")
 
@@ -429,12 +439,13 @@ def test_dc3d_full_golden(golden_dir):
     (d0 * dev(torch.from_numpy(z["full_bn/gout"]))).sum().backward()
     grads = dict(model.named_parameters())
     g64 = _fp64_oracle_grads(O.ST_DRAM_REF_MODEL, sd0, z["full_bn/x"], z["full_bn/gout"], "bn")
-    for k, gref in _sub(z, "full_bn/grad/").items():
-        check_grad(grads[k].grad, gref, g64[k], f"full grad {k}")
-    for k, v in _sub(z, "full_bn/gradnorm/").items():
-        got = grads[k].grad.double().norm().item()
+    check_grads({k: p.grad for k, p in grads.items()}, _sub(z, "full_bn/grad/"), g64, "full_bn")
+    ref_norms = _sub(z, "full_bn/gradnorm/")
+    nerr_ref = max(abs(float(v) - g64[k].norm().item()) / g64[k].norm().item() for k, v in ref_norms.items())
+    for k in ref_norms:
         n64 = g64[k].norm().item()
-        assert abs(got - n64) <= max(3.0 * abs(float(v) - n64), 5e-4 * n64), (k, got, float(v), n64)
+        got = grads[k].grad.double().norm().item()
+        assert abs(got - n64) / n64 <= max(3.0 * nerr_ref, 5e-4), (k, got, n64, nerr_ref)
     for k, v in _sub(z, "full_bn/sd_after/").items():
         check(model.state_dict()[k].double(), v.astype(np.float64), f"full buffer {k}")
     assert int(model.state_dict()["ds_modules.1.conv_blocks.0.1.num_batches_tracked"]) == 2
