@@ -25,6 +25,7 @@
 // The input of forward and the output of backward-data may be a *virtual*
 // channel concatenation of two tensors (crop_concat_5d fused away).
 #include "common.h"
+#include <stdlib.h>
 
 namespace dram {
 
@@ -53,20 +54,31 @@ struct ConvArgs {
 constexpr int KC = 4;  // input channels per LDS stage
 
 template <int BX, int BY, int BZ, int COT>
-__global__ __launch_bounds__(256) void conv3d_k3_fwd_kernel(ConvArgs a) {
-    static_assert(BX * BY * BZ == 256, "block covers 256 voxels");
-    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
-    constexpr int HV = HX * HY * HZ;
-    constexpr int PS = HV;
-    constexpr int COB = 32 * COT;
-    constexpr int NQ = (HV + 255) / 256;
-    constexpr int WROWS = 27 * KC;
-    constexpr int RPT = 256 / COB;  // weight rows staged per pass
-    constexpr int WPASS = (WROWS + RPT - 1) / RPT;
+struct FwdGeom {
+    static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    static constexpr int HV = HX * HY * HZ;
+    static constexpr int PS = HV;
+    static constexpr int COB = 32 * COT;
+    static constexpr int NQ = (HV + 255) / 256;
+    static constexpr int WROWS = 27 * KC;
+    static constexpr int RPT = 256 / COB;  // weight rows staged per pass
+    static constexpr int WPASS = (WROWS + RPT - 1) / RPT;
+    static constexpr int STAGE = KC * PS + WROWS * COB;  // floats per LDS stage
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
+};
 
-    __shared__ float lds[KC * PS + WROWS * COB];
-    float* lin = lds;
-    float* lw = lds + KC * PS;
+// Software pipeline (one barrier per K chunk): while the MFMAs of chunk c run out of LDS stage
+// c&1, the global loads of chunk c+1 are in flight into registers; they are written to the other
+// stage after the MFMAs and become visible at the barrier.  Two blocks (2 x 80 KB of LDS, 2 waves
+// per SIMD) share a CU, so one block's write/barrier phase is covered by the other's MFMAs.
+template <int BX, int BY, int BZ, int COT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
+    static_assert(BX * BY * BZ == 256, "block covers 256 voxels");
+    using G = FwdGeom<BX, BY, BZ, COT>;
+    constexpr int HX = G::HX, HY = G::HY, HV = G::HV, PS = G::PS, COB = G::COB, NQ = G::NQ;
+    constexpr int WROWS = G::WROWS, RPT = G::RPT, WPASS = G::WPASS, STAGE = G::STAGE;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
@@ -115,45 +127,56 @@ __global__ __launch_bounds__(256) void conv3d_k3_fwd_kernel(ConvArgs a) {
 
     const int wrow = tid / COB, wcol = tid % COB;
     const bool wcol_ok = (co0 + wcol) < a.Cout;
+    const float* wbase = a.wt + co0 + wcol;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-        __syncthreads();
-        // ---- stage KC input channels (zero padded halo) ----
+    float rin[KC][NQ];   // prefetched input halo elements of the next chunk
+    float rw[WPASS];     // prefetched weights of the next chunk
+
+    auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const int ci = c0 + kc;
-            float* dstp = lin + kc * PS;
-            // (two statically indexed copies: a runtime select between off1/off2 would push them to scratch)
+            // (statically indexed copies: a runtime select between off1/off2 would push them to scratch)
             if (ci >= a.Cin) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (tid + 256 * q < HV) dstp[tid + 256 * q] = 0.f;
+                for (int q = 0; q < NQ; ++q) rin[kc][q] = 0.f;
             } else if (ci < a.src.C1) {
                 const float* base = s1 + (size_t)ci * S;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (tid + 256 * q < HV) dstp[tid + 256 * q] = ok[q] ? base[off1[q]] : 0.f;
+                for (int q = 0; q < NQ; ++q) rin[kc][q] = ok[q] ? base[off1[q]] : 0.f;
             } else {
                 const float* base = s2 + (size_t)(ci - a.src.C1) * S2;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (tid + 256 * q < HV) dstp[tid + 256 * q] = ok[q] ? base[off2[q]] : 0.f;
+                for (int q = 0; q < NQ; ++q) rin[kc][q] = ok[q] ? base[off2[q]] : 0.f;
             }
         }
-        // ---- stage the weights of those channels: rows (tap,kc) x COB columns ----
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) {
             const int row = p * RPT + wrow;
-            if (row < WROWS) {
-                const int tap = row / KC, kc = row % KC;
-                const int ci = c0 + kc;
-                float v = 0.f;
-                if (ci < a.Cin && wcol_ok) v = a.wt[((size_t)tap * a.Cin + ci) * a.Cout + co0 + wcol];
-                lw[row * COB + wcol] = v;
-            }
+            const int tap = row / KC, kc = row % KC;
+            const int ci = c0 + kc;
+            float v = 0.f;
+            if (row < WROWS && ci < a.Cin && wcol_ok) v = wbase[((size_t)tap * a.Cin + ci) * a.Cout];
+            rw[p] = v;
         }
-        __syncthreads();
-        // ---- 27 taps x KC/2 k-steps of 32x32x2 MFMAs ----
+    };
+    auto store_chunk = [&](float* stage) {
+        float* lin = stage;
+        float* lw = stage + KC * PS;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (tid + 256 * q < HV) lin[kc * PS + tid + 256 * q] = rin[kc][q];
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) {
+            const int row = p * RPT + wrow;
+            if (row < WROWS) lw[row * COB + wcol] = rw[p];
+        }
+    };
+    auto compute = [&](const float* stage) {
+        const float* lin = stage;
+        const float* lw = stage + KC * PS;
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
@@ -172,6 +195,21 @@ __global__ __launch_bounds__(256) void conv3d_k3_fwd_kernel(ConvArgs a) {
                         acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
             }
         }
+    };
+
+    load_chunk(0);
+    store_chunk(lds);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+        const bool has_next = (c0 + KC) < a.Cin;
+        if (has_next) load_chunk(c0 + KC);          // global loads in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        compute(lds + cur * STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) store_chunk(lds + (cur ^ 1) * STAGE);
+        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: accumulator register r of lane (j,kh) = channel (r&3)+8(r>>2)+4kh, voxel j ----
@@ -216,19 +254,34 @@ struct PadTo2Mod32 {
     static constexpr int value = HVv + ((2 - (HVv % 32)) + 32) % 32;
 };
 
-template <int BX, int BY, int BZ>
-__global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(WgradArgs a) {
-    constexpr int VOX = BX * BY * BZ;
-    static_assert(VOX == 128 && BX % 4 == 0, "box = 128 voxels, rows a multiple of 4");
-    constexpr int PA = VOX + 2;  // co stride of the dY tile: == 2 (mod 32) -> conflict-free A reads
-    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
-    constexpr int HV = HX * HY * HZ;
-    constexpr int PB = PadTo2Mod32<HV>::value;  // ci stride of the X halo tile
-    constexpr int NQ = (HV + 255) / 256;
-    constexpr int CO_B = 64, CI_B = 16;
+// Software pipeline: the global loads of the next voxel box (dY and X halo, into registers) are in
+// flight while the MFMAs of the current box run; they are written to the (single-buffered) LDS tile
+// between two barriers afterwards.
+//   CSUB = 16-channel dY sub-tiles per wave (block covers 64*CSUB output channels)
+//   OCC  = blocks per CU the register budget is sized for (2 -> 256 VGPRs, 1 -> 512 VGPRs)
+template <int BX, int BY, int BZ, int CSUB>
+struct WgradGeom {
+    static constexpr int VOX = BX * BY * BZ;
+    static constexpr int PA = VOX + 2;  // co stride of the dY tile: == 2 (mod 32) -> conflict-free A reads
+    static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    static constexpr int HV = HX * HY * HZ;
+    static constexpr int PB = PadTo2Mod32<HV>::value;  // ci stride of the X halo tile
+    static constexpr int NQ = (HV + 255) / 256;
+    static constexpr int CO_B = 64 * CSUB, CI_B = 16;
+    static constexpr int ROWS_PER_PASS = 256 / VOX;     // dY channel rows staged per pass
+    static constexpr int DYQ = CO_B / ROWS_PER_PASS;    // dY registers per thread
+    static constexpr size_t LDS_BYTES = (size_t)(CO_B * PA + CI_B * PB) * sizeof(float);
+};
+
+template <int BX, int BY, int BZ, int CSUB, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) {
+    using G = WgradGeom<BX, BY, BZ, CSUB>;
+    constexpr int VOX = G::VOX, PA = G::PA, HX = G::HX, HY = G::HY, HV = G::HV, PB = G::PB, NQ = G::NQ;
+    constexpr int CO_B = G::CO_B, CI_B = G::CI_B, RPP = G::ROWS_PER_PASS, DYQ = G::DYQ;
+    static_assert(256 % VOX == 0 && BX % 4 == 0 && PA % 32 == 2, "box geometry");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldy = lds;             // [64][PA]
+    float* ldy = lds;             // [CO_B][PA]
     float* lx = lds + CO_B * PA;  // [16][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -241,39 +294,38 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     const int S = D * H * W;
     const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
 
-    f32x4 acc[27];
+    f32x4 acc[CSUB][27];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < CSUB; ++u)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int i = lane & 15, k = lane >> 4;
-    // dY staging role: voxel v_st, channel rows co_st + 2q
+    // dY staging role: voxel v_st, channel rows co_st + RPP*q
     const int v_st = tid % VOX, co_st = tid / VOX;
     const int svx = v_st % BX, svy = (v_st / BX) % BY, svz = v_st / (BX * BY);
 
-    for (int box = sp; box < a.nboxes; box += a.split) {
+    float rdy[DYQ];
+    float rx[CI_B][NQ];
+
+    auto load_box = [&](int box) {
         int bb = box;
         const int bx = bb % a.nbx; bb /= a.nbx;
         const int by = bb % a.nby; bb /= a.nby;
         const int bz = bb % a.nbz;
         const int n = bb / a.nbz;
         const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-
-        __syncthreads();
-        // ---- stage dY[64 co][128 voxels] ----
-        {
+        {   // dY[CO_B][VOX]
             const int gx = x0 + svx, gy = y0 + svy, gz = z0 + svz;
             const bool vok = gx < W && gy < H && gz < D;
             const float* dyn = a.dy + ((size_t)n * a.Cout + co0) * S + (gz * H + gy) * W + gx;
-#pragma unroll 8
-            for (int q = 0; q < CO_B / 2; ++q) {
-                const int co = co_st + 2 * q;
-                float v = 0.f;
-                if (vok && (co0 + co) < a.Cout) v = dyn[(size_t)co * S];
-                ldy[co * PA + v_st] = v;
+#pragma unroll
+            for (int q = 0; q < DYQ; ++q) {
+                const int co = co_st + RPP * q;
+                rdy[q] = (vok && (co0 + co) < a.Cout) ? dyn[(size_t)co * S] : 0.f;
             }
         }
-        // ---- stage X[16 ci][halo] ----
-        {
+        {   // X[16 ci][halo]
             int off1[NQ], off2[NQ];
             bool ok[NQ];
 #pragma unroll
@@ -287,42 +339,70 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(WgradArgs a) {
             }
             const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
             const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : nullptr;
-#pragma unroll 4
+#pragma unroll
             for (int c = 0; c < CI_B; ++c) {
                 const int ci = ci0 + c;
-                float* dstp = lx + c * PB;
                 if (ci >= a.Cin) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (tid + 256 * q < HV) dstp[tid + 256 * q] = 0.f;
+                    for (int q = 0; q < NQ; ++q) rx[c][q] = 0.f;
                 } else if (ci < a.src.C1) {
                     const float* base = s1 + (size_t)ci * S;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (tid + 256 * q < HV) dstp[tid + 256 * q] = ok[q] ? base[off1[q]] : 0.f;
+                    for (int q = 0; q < NQ; ++q) rx[c][q] = ok[q] ? base[off1[q]] : 0.f;
                 } else {
                     const float* base = s2 + (size_t)(ci - a.src.C1) * S2;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (tid + 256 * q < HV) dstp[tid + 256 * q] = ok[q] ? base[off2[q]] : 0.f;
+                    for (int q = 0; q < NQ; ++q) rx[c][q] = ok[q] ? base[off2[q]] : 0.f;
                 }
             }
         }
-        __syncthreads();
-        // ---- 32 k-steps (4 voxels along x each) x 27 taps of 16x16x4 MFMAs ----
-        const float* ap = ldy + (wave * 16 + i) * PA + k;
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int q = 0; q < DYQ; ++q) ldy[(co_st + RPP * q) * PA + v_st] = rdy[q];
+#pragma unroll
+        for (int c = 0; c < CI_B; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (tid + 256 * q < HV) lx[c * PB + tid + 256 * q] = rx[c][q];
+    };
+    auto compute = [&]() {
+        // VOX/4 k-steps (4 voxels along x each) x 27 taps x CSUB of 16x16x4 MFMAs
+        const float* ap = ldy + (wave * 16 * CSUB + i) * PA + k;
         const float* bp = lx + i * PB + k;
 #pragma unroll 2
         for (int ks = 0; ks < VOX / 4; ++ks) {
             const int x4 = ks % (BX / 4), vy = (ks / (BX / 4)) % BY, vz = ks / ((BX / 4) * BY);
-            const float av = ap[(vz * BY + vy) * BX + 4 * x4];
+            float av[CSUB];
+#pragma unroll
+            for (int u = 0; u < CSUB; ++u) av[u] = ap[16 * u * PA + (vz * BY + vy) * BX + 4 * x4];
             const float* bq = bp + (vz * HY + vy) * HX + 4 * x4;
 #pragma unroll
             for (int tap = 0; tap < 27; ++tap) {
                 const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
                 const float bv = bq[(dz * HY + dy) * HX + dx];
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tap], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < CSUB; ++u)
+                    acc[u][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv, acc[u][tap], 0, 0, 0);
             }
+        }
+    };
+
+    if (sp < a.nboxes) {
+        load_box(sp);
+        store_box();
+    }
+    __syncthreads();
+    for (int box = sp; box < a.nboxes; box += a.split) {
+        const bool has_next = (box + a.split) < a.nboxes;
+        if (has_next) load_box(box + a.split);      // global loads in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+            __syncthreads();                         // every wave is done reading the tile
+            store_box();
+            __syncthreads();
         }
     }
 
@@ -330,14 +410,16 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     const int ci = ci0 + i;
     if (ci < a.Cin) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wave * 16 + 4 * k + r;
-            if (co < a.Cout) {
-                float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
+        for (int u = 0; u < CSUB; ++u)
 #pragma unroll
-                for (int tap = 0; tap < 27; ++tap) o[tap] = acc[tap][r];
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wave * CSUB + u) * 16 + 4 * k + r;
+                if (co < a.Cout) {
+                    float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
+#pragma unroll
+                    for (int tap = 0; tap < 27; ++tap) o[tap] = acc[u][tap][r];
+                }
             }
-        }
     }
 }
 
@@ -367,6 +449,24 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+template <int BX, int BY, int BZ, int COT>
+static int launch_fwd_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
+    using G = FwdGeom<BX, BY, BZ, COT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_fwd_kernel<BX, BY, BZ, COT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("conv3d_k3_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DRAM_EHIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(nblk, cdiv(a.Cout, 32 * COT));
+    hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, COT>), grid, dim3(256), G::LDS_BYTES, st, a);
+    return check_launch("conv3d_k3_fwd");
+}
+
 template <int BX, int BY, int BZ>
 static int launch_fwd(ConvArgs& a, hipStream_t st) {
     a.nbx = cdiv(a.W, BX);
@@ -377,14 +477,8 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    if (a.Cout <= 32) {
-        dim3 grid((unsigned)nblk, cdiv(a.Cout, 32));
-        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, 1>), grid, dim3(256), 0, st, a);
-    } else {
-        dim3 grid((unsigned)nblk, cdiv(a.Cout, 64));
-        hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, 2>), grid, dim3(256), 0, st, a);
-    }
-    return check_launch("conv3d_k3_fwd");
+    if (a.Cout <= 32) return launch_fwd_cot<BX, BY, BZ, 1>(a, (unsigned)nblk, st);
+    return launch_fwd_cot<BX, BY, BZ, 2>(a, (unsigned)nblk, st);
 }
 
 static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
@@ -394,37 +488,52 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
 }
 
 struct WgradPlan {
+    int variant;  // 0: 64-voxel boxes, 64 co, 2 blocks/CU;  1: 128-voxel boxes, 128 co, 1 block/CU (512 VGPRs)
     int bx, by, bz, nbx, nby, nbz, nboxes, ci_tiles, co_tiles, split;
 };
 
+static int wgrad_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DRAM_WGRAD_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W) {
     WgradPlan p;
-    if (W >= 24) { p.bx = 32; p.by = 2; p.bz = 2; }
-    else if (W >= 12) { p.bx = 16; p.by = 4; p.bz = 2; }
-    else { p.bx = 8; p.by = 4; p.bz = 4; }
+    p.variant = (wgrad_variant() == 1 && Cout > 64) ? 1 : 0;
+    const int wclass = W >= 24 ? 32 : (W >= 12 ? 16 : 8);
+    if (p.variant == 1) {
+        if (wclass == 32) { p.bx = 32; p.by = 2; p.bz = 2; }
+        else if (wclass == 16) { p.bx = 16; p.by = 4; p.bz = 2; }
+        else { p.bx = 8; p.by = 4; p.bz = 4; }
+    } else {
+        if (wclass == 32) { p.bx = 32; p.by = 2; p.bz = 1; }
+        else if (wclass == 16) { p.bx = 16; p.by = 2; p.bz = 2; }
+        else { p.bx = 8; p.by = 4; p.bz = 2; }
+    }
     p.nbx = cdiv(W, p.bx); p.nby = cdiv(H, p.by); p.nbz = cdiv(D, p.bz);
     const int64_t nb = (int64_t)N * p.nbx * p.nby * p.nbz;
     p.nboxes = (int)nb;
     p.ci_tiles = cdiv(Cin, 16);
-    p.co_tiles = cdiv(Cout, 64);
+    p.co_tiles = cdiv(Cout, p.variant == 1 ? 128 : 64);
     const int tiles = p.ci_tiles * p.co_tiles;
-    int split = cdiv(1024, tiles);  // ~4 blocks per CU in flight over the whole launch
+    int split = cdiv(p.variant == 1 ? 512 : 1024, tiles);  // ~2 rounds of resident blocks over the launch
     if (split > p.nboxes) split = p.nboxes;
     if (split < 1) split = 1;
     p.split = split;
     return p;
 }
 
-template <int BX, int BY, int BZ>
+template <int BX, int BY, int BZ, int CSUB, int OCC>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
-    constexpr int VOX = BX * BY * BZ;
-    constexpr int HV = (BX + 2) * (BY + 2) * (BZ + 2);
-    constexpr int PB = PadTo2Mod32<HV>::value;
-    constexpr size_t lds_bytes = (size_t)(64 * (VOX + 2) + 16 * PB) * sizeof(float);
+    using G = WgradGeom<BX, BY, BZ, CSUB>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ, CSUB, OCC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess) {
             set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DRAM_EHIP;
@@ -432,7 +541,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<BX, BY, BZ>), dim3(grid), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<BX, BY, BZ, CSUB, OCC>), dim3(grid), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad");
 }
 
@@ -537,9 +646,15 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     a.nbx = p.nbx; a.nby = p.nby; a.nbz = p.nbz; a.nboxes = p.nboxes;
     a.split = p.split; a.ci_tiles = p.ci_tiles; a.co_tiles = p.co_tiles;
     hipStream_t st = (hipStream_t)stream;
-    if (p.bx == 32) rc = launch_wgrad<32, 2, 2>(a, st);
-    else if (p.bx == 16) rc = launch_wgrad<16, 4, 2>(a, st);
-    else rc = launch_wgrad<8, 4, 4>(a, st);
+    if (p.variant == 1) {
+        if (p.bx == 32) rc = launch_wgrad<32, 2, 2, 2, 1>(a, st);
+        else if (p.bx == 16) rc = launch_wgrad<16, 4, 2, 2, 1>(a, st);
+        else rc = launch_wgrad<8, 4, 4, 2, 1>(a, st);
+    } else {
+        if (p.bx == 32) rc = launch_wgrad<32, 2, 1, 1, 2>(a, st);
+        else if (p.bx == 16) rc = launch_wgrad<16, 2, 2, 1, 2>(a, st);
+        else rc = launch_wgrad<8, 4, 2, 1, 2>(a, st);
+    }
     if (rc) return rc;
     const int64_t E = (int64_t)Cout * a.Cin * 27;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, a.slabs, dw, E, p.split);
