@@ -67,16 +67,39 @@ struct FwdGeom {
     static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
 };
 
+// Buffer (SRD) loads: 32-bit per-lane byte offset against a wave-uniform descriptor.  Offsets at or
+// beyond num_records return 0, so zero padding (volume border, channel tails) needs neither a
+// branch nor a select -- and a branch around a load would make hipcc wait vmcnt(0) per element.
+constexpr unsigned OOB = 0x80000000u;   // > any plane size in bytes (check_conv_shape)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // Software pipeline (one barrier per K chunk): while the MFMAs of chunk c run out of LDS stage
 // c&1, the global loads of chunk c+1 are in flight into registers; they are written to the other
-// stage after the MFMAs and become visible at the barrier.  Two blocks (2 x 80 KB of LDS, 2 waves
-// per SIMD) share a CU, so one block's write/barrier phase is covered by the other's MFMAs.
+// stage after the MFMAs and become visible at the barrier.  Inside a chunk the LDS operand reads
+// of k-step s+1 are issued ahead of the MFMAs of k-step s (two operand register sets).  Two blocks
+// (2 x 80 KB of LDS, 2 waves per SIMD) share a CU, so one block's write/barrier phase is covered
+// by the other's MFMAs.
 template <int BX, int BY, int BZ, int COT>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     static_assert(BX * BY * BZ == 256, "block covers 256 voxels");
     using G = FwdGeom<BX, BY, BZ, COT>;
     constexpr int HX = G::HX, HY = G::HY, HV = G::HV, PS = G::PS, COB = G::COB, NQ = G::NQ;
     constexpr int WROWS = G::WROWS, RPT = G::RPT, WPASS = G::WPASS, STAGE = G::STAGE;
+    static_assert(NQ <= 4, "halo elements per thread");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -92,20 +115,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     const int S = D * H * W;
     const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
 
-    // per-thread halo elements of the input stage
-    int off1[NQ], off2[NQ];
-    bool ok[NQ];
+    // per-thread halo elements of the input stage: byte offsets inside one channel plane
+    u32x4 off1, off2;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int e = tid + 256 * q;
         const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
         const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-        ok[q] = (e < HV) && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
-        off1[q] = (gz * H + gy) * W + gx;
-        off2[q] = ((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox;
+        const bool ok = (q < NQ) && (e < HV) && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        off1[q] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+        off2[q] = ok ? 4u * (unsigned)(((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
     }
     const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
-    const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : nullptr;
+    const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
 
     f32x16 acc[COT][2];
 #pragma unroll
@@ -125,9 +147,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     }
     const int abase = kh * COB + j;
 
+    // weights: thread (wrow, wcol) stages rows p*RPT + wrow, p = 0..WPASS-1 of the [27*KC][COB] tile
     const int wrow = tid / COB, wcol = tid % COB;
     const bool wcol_ok = (co0 + wcol) < a.Cout;
-    const float* wbase = a.wt + co0 + wcol;
+    const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 27u * (unsigned)a.Cin * (unsigned)a.Cout * 4u);
+    const unsigned tap_stride = 4u * (unsigned)a.Cin * (unsigned)a.Cout;
 
     float rin[KC][NQ];   // prefetched input halo elements of the next chunk
     float rw[WPASS];     // prefetched weights of the next chunk
@@ -135,29 +159,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            const int ci = c0 + kc;
-            // (statically indexed copies: a runtime select between off1/off2 would push them to scratch)
-            if (ci >= a.Cin) {
+            const int ci = c0 + kc;                      // wave-uniform
+            const bool first = ci < a.src.C1;
+            const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
+            const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;   // 0 records: all zeros
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(plane), bytes);
+            const u32x4 off = first ? off1 : off2;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) rin[kc][q] = 0.f;
-            } else if (ci < a.src.C1) {
-                const float* base = s1 + (size_t)ci * S;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) rin[kc][q] = ok[q] ? base[off1[q]] : 0.f;
-            } else {
-                const float* base = s2 + (size_t)(ci - a.src.C1) * S2;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) rin[kc][q] = ok[q] ? base[off2[q]] : 0.f;
-            }
+            for (int q = 0; q < NQ; ++q) rin[kc][q] = buf_load(srd, off[q], 0);
         }
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) {
             const int row = p * RPT + wrow;
             const int tap = row / KC, kc = row % KC;
             const int ci = c0 + kc;
-            float v = 0.f;
-            if (row < WROWS && ci < a.Cin && wcol_ok) v = wbase[((size_t)tap * a.Cin + ci) * a.Cout];
-            rw[p] = v;
+            const bool ok = (RPT * WPASS == WROWS || row < WROWS) && ci < a.Cin && wcol_ok;
+            const unsigned voff = ok ? 4u * (unsigned)(ci * a.Cout + co0 + wcol) : OOB;
+            if (RPT == KC) {   // COB == 64: tap == p is uniform -> scalar offset
+                rw[p] = buf_load(wsrd, voff, (unsigned)p * tap_stride);
+            } else {
+                rw[p] = buf_load(wsrd, ok ? voff + (unsigned)tap * tap_stride : OOB, 0);
+            }
         }
     };
     auto store_chunk = [&](float* stage) {
@@ -171,29 +193,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) {
             const int row = p * RPT + wrow;
-            if (row < WROWS) lw[row * COB + wcol] = rw[p];
+            if (RPT * WPASS == WROWS || row < WROWS) lw[row * COB + wcol] = rw[p];
         }
     };
     auto compute = [&](const float* stage) {
         const float* lin = stage;
         const float* lw = stage + KC * PS;
+        constexpr int NS = 27 * (KC / 2);   // k-steps of this chunk
+        float av[2][COT], bv[2][2];
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const int toff = (dz * HY + dy) * HX + dx;
+        for (int s = 0; s <= NS; ++s) {
+            if (s < NS) {      // operands of k-step s -> register set s&1
+                const int tap = s / (KC / 2), kk = s % (KC / 2);
+                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                const int toff = (dz * HY + dy) * HX + dx;
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float av[COT], bv[2];
+                for (int c = 0; c < COT; ++c) av[s & 1][c] = lw[abase + (tap * KC + 2 * kk) * COB + 32 * c];
 #pragma unroll
-                for (int c = 0; c < COT; ++c) av[c] = lw[abase + (tap * KC + 2 * kk) * COB + 32 * c];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) bv[t] = lin[bbase[t] + 2 * kk * PS + toff];
+                for (int t = 0; t < 2; ++t) bv[s & 1][t] = lin[bbase[t] + 2 * kk * PS + toff];
+            }
+            if (s > 0) {       // MFMAs of k-step s-1
 #pragma unroll
                 for (int c = 0; c < COT; ++c)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
-                        acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[t], acc[c][t], 0, 0, 0);
+                        acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s - 1) & 1][c], bv[(s - 1) & 1][t],
+                                                                          acc[c][t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, COT + 2, 0);   // DS reads of step s ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * COT, 0);   // ... then MFMAs of step s-1
         }
     };
 
@@ -254,37 +282,44 @@ struct PadTo2Mod32 {
     static constexpr int value = HVv + ((2 - (HVv % 32)) + 32) % 32;
 };
 
-// Software pipeline: the global loads of the next voxel box (dY and X halo, into registers) are in
-// flight while the MFMAs of the current box run; they are written to the (single-buffered) LDS tile
-// between two barriers afterwards.
-//   CSUB = 16-channel dY sub-tiles per wave (block covers 64*CSUB output channels)
-//   OCC  = blocks per CU the register budget is sized for (2 -> 256 VGPRs, 1 -> 512 VGPRs)
-template <int BX, int BY, int BZ, int CSUB>
+// backward-weights kernel: one 512-thread block (8 waves, two per SIMD) per CU.
+//   block tile = (16*COS output channels) x (16*CIT input channels) x 27 taps, COS*CIT = 8 waves;
+//   each wave owns one 16x16 (co,ci) sub-tile for all 27 taps (27 accumulators of 4 registers).
+//   COS=8,CIT=1 for wide layers; COS=4,CIT=2 when Cout <= 64 (the full-resolution layers).
+// Software pipeline: the global loads of the next 64-voxel box (dY and X halo, <= 48 registers per
+// thread, buffer loads with hardware zero fill) are in flight while the MFMAs of the current box
+// run; they are written to the single-buffered LDS tile between two barriers afterwards.  Inside
+// a box the LDS operand reads of k-step s+1 are issued ahead of the MFMAs of k-step s.
+template <int BX, int BY, int BZ, int COS, int CIT>
 struct WgradGeom {
+    static constexpr int T = 512;
     static constexpr int VOX = BX * BY * BZ;
     static constexpr int PA = VOX + 2;  // co stride of the dY tile: == 2 (mod 32) -> conflict-free A reads
     static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
     static constexpr int HV = HX * HY * HZ;
     static constexpr int PB = PadTo2Mod32<HV>::value;  // ci stride of the X halo tile
-    static constexpr int NQ = (HV + 255) / 256;
-    static constexpr int CO_B = 64 * CSUB, CI_B = 16;
-    static constexpr int ROWS_PER_PASS = 256 / VOX;     // dY channel rows staged per pass
+    static constexpr int NQ = (HV + T - 1) / T;
+    static constexpr int CO_B = 16 * COS, CI_B = 16 * CIT;
+    static constexpr int ROWS_PER_PASS = T / VOX;       // dY channel rows staged per pass
     static constexpr int DYQ = CO_B / ROWS_PER_PASS;    // dY registers per thread
     static constexpr size_t LDS_BYTES = (size_t)(CO_B * PA + CI_B * PB) * sizeof(float);
 };
 
-template <int BX, int BY, int BZ, int CSUB, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) {
-    using G = WgradGeom<BX, BY, BZ, CSUB>;
-    constexpr int VOX = G::VOX, PA = G::PA, HX = G::HX, HY = G::HY, HV = G::HV, PB = G::PB, NQ = G::NQ;
+template <int BX, int BY, int BZ, int COS, int CIT>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
+    using G = WgradGeom<BX, BY, BZ, COS, CIT>;
+    constexpr int T = G::T, VOX = G::VOX, PA = G::PA, HX = G::HX, HY = G::HY, HV = G::HV, PB = G::PB, NQ = G::NQ;
     constexpr int CO_B = G::CO_B, CI_B = G::CI_B, RPP = G::ROWS_PER_PASS, DYQ = G::DYQ;
-    static_assert(256 % VOX == 0 && BX % 4 == 0 && PA % 32 == 2, "box geometry");
+    static_assert(COS * CIT == 8 && T % VOX == 0 && VOX % 64 == 0 && BX % 4 == 0 && PA % 32 == 2 && NQ <= 2 &&
+                      CO_B % RPP == 0, "block geometry");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ldy = lds;             // [CO_B][PA]
-    float* lx = lds + CO_B * PA;  // [16][PB]
+    float* lx = lds + CO_B * PA;  // [CI_B][PB]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % COS, wci = wave / COS;   // this wave's (co, ci) sub-tile
     int b = blockIdx.x;
     const int ci_t = b % a.ci_tiles; b /= a.ci_tiles;
     const int co_t = b % a.co_tiles;
@@ -294,15 +329,14 @@ __global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) 
     const int S = D * H * W;
     const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
 
-    f32x4 acc[CSUB][27];
+    f32x4 acc[27];
 #pragma unroll
-    for (int u = 0; u < CSUB; ++u)
-#pragma unroll
-        for (int t = 0; t < 27; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int i = lane & 15, k = lane >> 4;
-    // dY staging role: voxel v_st, channel rows co_st + RPP*q
-    const int v_st = tid % VOX, co_st = tid / VOX;
+    // dY staging role: voxel v_st of the box, channel rows co_st + RPP*q (co_st is wave-uniform)
+    const int v_st = tid % VOX;
+    const int co_st = __builtin_amdgcn_readfirstlane(tid / VOX);
     const int svx = v_st % BX, svy = (v_st / BX) % BY, svz = v_st / (BX * BY);
 
     float rdy[DYQ];
@@ -315,45 +349,41 @@ __global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) 
         const int bz = bb % a.nbz;
         const int n = bb / a.nbz;
         const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-        {   // dY[CO_B][VOX]
+        {   // dY[CO_B][VOX]: one descriptor per sample, channel row as a scalar offset
             const int gx = x0 + svx, gy = y0 + svy, gz = z0 + svz;
             const bool vok = gx < W && gy < H && gz < D;
-            const float* dyn = a.dy + ((size_t)n * a.Cout + co0) * S + (gz * H + gy) * W + gx;
+            const unsigned voff = vok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+            const __amdgpu_buffer_rsrc_t srd =
+                make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), 4u * (unsigned)a.Cout * (unsigned)S);
 #pragma unroll
             for (int q = 0; q < DYQ; ++q) {
-                const int co = co_st + RPP * q;
-                rdy[q] = (vok && (co0 + co) < a.Cout) ? dyn[(size_t)co * S] : 0.f;
+                const int co = co0 + co_st + RPP * q;            // wave-uniform
+                const bool cok = co < a.Cout;
+                rdy[q] = buf_load(srd, cok ? voff : OOB, cok ? 4u * (unsigned)co * (unsigned)S : 0u);
             }
         }
-        {   // X[16 ci][halo]
-            int off1[NQ], off2[NQ];
-            bool ok[NQ];
+        {   // X[CI_B][halo]: one descriptor per channel plane (0 records beyond Cin -> zeros)
+            unsigned off1[NQ], off2[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int e = tid + 256 * q;
+                const int e = tid + T * q;
                 const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
                 const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                ok[q] = (e < HV) && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
-                off1[q] = (gz * H + gy) * W + gx;
-                off2[q] = ((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox;
+                const bool ok = (e < HV) && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+                off1[q] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+                off2[q] = ok ? 4u * (unsigned)(((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
             }
             const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
-            const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : nullptr;
+            const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
 #pragma unroll
             for (int c = 0; c < CI_B; ++c) {
                 const int ci = ci0 + c;
-                if (ci >= a.Cin) {
+                const bool first = ci < a.src.C1;
+                const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
+                const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;
+                const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(plane), bytes);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) rx[c][q] = 0.f;
-                } else if (ci < a.src.C1) {
-                    const float* base = s1 + (size_t)ci * S;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) rx[c][q] = ok[q] ? base[off1[q]] : 0.f;
-                } else {
-                    const float* base = s2 + (size_t)(ci - a.src.C1) * S2;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) rx[c][q] = ok[q] ? base[off2[q]] : 0.f;
-                }
+                for (int q = 0; q < NQ; ++q) rx[c][q] = buf_load(srd, first ? off1[q] : off2[q], 0);
             }
         }
     };
@@ -364,27 +394,32 @@ __global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) 
         for (int c = 0; c < CI_B; ++c)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (tid + 256 * q < HV) lx[c * PB + tid + 256 * q] = rx[c][q];
+                if (tid + T * q < HV) lx[c * PB + tid + T * q] = rx[c][q];
     };
     auto compute = [&]() {
-        // VOX/4 k-steps (4 voxels along x each) x 27 taps x CSUB of 16x16x4 MFMAs
-        const float* ap = ldy + (wave * 16 * CSUB + i) * PA + k;
-        const float* bp = lx + i * PB + k;
-#pragma unroll 2
-        for (int ks = 0; ks < VOX / 4; ++ks) {
-            const int x4 = ks % (BX / 4), vy = (ks / (BX / 4)) % BY, vz = ks / ((BX / 4) * BY);
-            float av[CSUB];
+        // VOX/4 k-steps (4 voxels along x each) x 27 taps of 16x16x4 MFMAs
+        const float* ap = ldy + (wco * 16 + i) * PA + k;
+        const float* bp = lx + (wci * 16 + i) * PB + k;
+        constexpr int NS = VOX / 4;
+        float av[2], bv[2][27];
 #pragma unroll
-            for (int u = 0; u < CSUB; ++u) av[u] = ap[16 * u * PA + (vz * BY + vy) * BX + 4 * x4];
-            const float* bq = bp + (vz * HY + vy) * HX + 4 * x4;
+        for (int s = 0; s <= NS; ++s) {
+            if (s < NS) {
+                const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
+                av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
+                const float* bq = bp + (vz * HY + vy) * HX + 4 * x4;
 #pragma unroll
-            for (int tap = 0; tap < 27; ++tap) {
-                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const float bv = bq[(dz * HY + dy) * HX + dx];
-#pragma unroll
-                for (int u = 0; u < CSUB; ++u)
-                    acc[u][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv, acc[u][tap], 0, 0, 0);
+                for (int tap = 0; tap < 27; ++tap) {
+                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                    bv[s & 1][tap] = bq[(dz * HY + dy) * HX + dx];
+                }
             }
+            if (s > 0) {
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(s - 1) & 1], bv[(s - 1) & 1][tap], acc[tap], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep exactly two operand sets live: reads(s) + MFMAs(s-1) per region
         }
     };
 
@@ -407,19 +442,17 @@ __global__ __launch_bounds__(256, OCC) void conv3d_k3_wgrad_kernel(WgradArgs a) 
     }
 
     // ---- partial slab: D row = co (4*(lane>>4)+r), col = ci (lane&15) ----
-    const int ci = ci0 + i;
+    const int ci = ci0 + wci * 16 + i;
     if (ci < a.Cin) {
 #pragma unroll
-        for (int u = 0; u < CSUB; ++u)
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wco * 16 + 4 * k + r;
+            if (co < a.Cout) {
+                float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + (wave * CSUB + u) * 16 + 4 * k + r;
-                if (co < a.Cout) {
-                    float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
-#pragma unroll
-                    for (int tap = 0; tap < 27; ++tap) o[tap] = acc[u][tap][r];
-                }
+                for (int tap = 0; tap < 27; ++tap) o[tap] = acc[tap][r];
             }
+        }
     }
 }
 
@@ -488,51 +521,50 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
 }
 
 struct WgradPlan {
-    int variant;  // 0: 64-voxel boxes, 64 co, 2 blocks/CU;  1: 128-voxel boxes, 128 co, 1 block/CU (512 VGPRs)
+    int variant;  // 0: block = 64 co x 32 ci (Cout <= 64);  1: block = 128 co x 16 ci
     int bx, by, bz, nbx, nby, nbz, nboxes, ci_tiles, co_tiles, split;
 };
 
-static int wgrad_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DRAM_WGRAD_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W) {
     WgradPlan p;
-    p.variant = (wgrad_variant() == 1 && Cout > 64) ? 1 : 0;
-    const int wclass = W >= 24 ? 32 : (W >= 12 ? 16 : 8);
-    if (p.variant == 1) {
-        if (wclass == 32) { p.bx = 32; p.by = 2; p.bz = 2; }
-        else if (wclass == 16) { p.bx = 16; p.by = 4; p.bz = 2; }
-        else { p.bx = 8; p.by = 4; p.bz = 4; }
-    } else {
-        if (wclass == 32) { p.bx = 32; p.by = 2; p.bz = 1; }
-        else if (wclass == 16) { p.bx = 16; p.by = 2; p.bz = 2; }
-        else { p.bx = 8; p.by = 4; p.bz = 2; }
-    }
+    p.variant = Cout > 64 ? 1 : 0;
+    if (W >= 24) { p.bx = 32; p.by = 2; p.bz = 1; }
+    else if (W >= 12) { p.bx = 16; p.by = 2; p.bz = 2; }
+    else { p.bx = 8; p.by = 4; p.bz = 2; }
     p.nbx = cdiv(W, p.bx); p.nby = cdiv(H, p.by); p.nbz = cdiv(D, p.bz);
     const int64_t nb = (int64_t)N * p.nbx * p.nby * p.nbz;
     p.nboxes = (int)nb;
-    p.ci_tiles = cdiv(Cin, 16);
+    p.ci_tiles = cdiv(Cin, p.variant == 1 ? 16 : 32);
     p.co_tiles = cdiv(Cout, p.variant == 1 ? 128 : 64);
+    // Blocks = tiles x split, one 512-thread block resident per CU (256 at a time).  A last round
+    // that is nearly empty costs a whole block duration (measured: 1032 blocks on 512 slots ran 1.5x
+    // longer than 1020), so pick the split with the best slot utilisation, preferring >= 2 rounds.
     const int tiles = p.ci_tiles * p.co_tiles;
-    int split = cdiv(p.variant == 1 ? 512 : 1024, tiles);  // ~2 rounds of resident blocks over the launch
-    if (split > p.nboxes) split = p.nboxes;
-    if (split < 1) split = 1;
-    p.split = split;
+    const int resident = 256;
+    const size_t slab = (size_t)Cout * Cin * 27 * sizeof(float);
+    int best = 1;
+    double best_score = -1.0;
+    for (int sp = 1; sp <= p.nboxes && sp <= 4096; ++sp) {
+        const int64_t blocks = (int64_t)tiles * sp;
+        if (blocks > 4LL * resident && sp > 1) break;
+        if ((size_t)sp * slab > ((size_t)1 << 30) && sp > 1) break;
+        const int64_t rounds = (blocks + resident - 1) / resident;
+        double util = (double)blocks / (double)(rounds * resident);
+        const int64_t per = (p.nboxes + sp - 1) / sp;   // uneven box counts per block also idle slots
+        util *= (double)p.nboxes / (double)(per * sp);
+        const double score = util + 1e-3 * (blocks >= 2LL * resident ? 1.0 : (double)blocks / (2.0 * resident));
+        if (score > best_score) { best_score = score; best = sp; }
+    }
+    p.split = best;
     return p;
 }
 
-template <int BX, int BY, int BZ, int CSUB, int OCC>
+template <int BX, int BY, int BZ, int COS, int CIT>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
-    using G = WgradGeom<BX, BY, BZ, CSUB>;
+    using G = WgradGeom<BX, BY, BZ, COS, CIT>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ, CSUB, OCC>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ, COS, CIT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess) {
             set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -541,14 +573,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<BX, BY, BZ, CSUB, OCC>), dim3(grid), dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<BX, BY, BZ, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad");
 }
 
 static int check_conv_shape(const char* who, int N, int Cin, int Cout, int D, int H, int W) {
     DRAM_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "%s: non-positive dimension", who);
-    DRAM_REQUIRE((int64_t)D * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < 0x7fffffffLL,
-                 "%s: one sample exceeds 2^31 elements", who);
+    DRAM_REQUIRE((int64_t)D * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < 0x3fffffffLL,
+                 "%s: one sample exceeds 2^30 elements (32-bit buffer descriptors)", who);
     return DRAM_OK;
 }
 
@@ -647,13 +679,13 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     a.split = p.split; a.ci_tiles = p.ci_tiles; a.co_tiles = p.co_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (p.variant == 1) {
-        if (p.bx == 32) rc = launch_wgrad<32, 2, 2, 2, 1>(a, st);
-        else if (p.bx == 16) rc = launch_wgrad<16, 4, 2, 2, 1>(a, st);
-        else rc = launch_wgrad<8, 4, 4, 2, 1>(a, st);
+        if (p.bx == 32) rc = launch_wgrad<32, 2, 1, 8, 1>(a, st);
+        else if (p.bx == 16) rc = launch_wgrad<16, 2, 2, 8, 1>(a, st);
+        else rc = launch_wgrad<8, 4, 2, 8, 1>(a, st);
     } else {
-        if (p.bx == 32) rc = launch_wgrad<32, 2, 1, 1, 2>(a, st);
-        else if (p.bx == 16) rc = launch_wgrad<16, 2, 2, 1, 2>(a, st);
-        else rc = launch_wgrad<8, 4, 2, 1, 2>(a, st);
+        if (p.bx == 32) rc = launch_wgrad<32, 2, 1, 4, 2>(a, st);
+        else if (p.bx == 16) rc = launch_wgrad<16, 2, 2, 4, 2>(a, st);
+        else rc = launch_wgrad<8, 4, 2, 4, 2>(a, st);
     }
     if (rc) return rc;
     const int64_t E = (int64_t)Cout * a.Cin * 27;
