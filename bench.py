@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--size", type=int, default=128, help="chunk edge (metric: 128)")
     ap.add_argument("--micro", type=int, default=16, help="micro-batch (chunks) for gradient accumulation")
     ap.add_argument("--norm", default="bn", help="norm_method of the model (reference default: bn)")
+    ap.add_argument("--checkpoint-mode", default="stats", choices=["stats", "recompute"],
+                    help="how checkpoint_layers flags are honoured (models.DC3D.checkpoint_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
@@ -132,6 +134,7 @@ def main():
     torch.manual_seed(0)                                   # same initial replica on every rank
     model = models.DC3D(**ST_DRAM_REF_MODEL, norm_method=args.norm)
     model.init(models.HeNorm(mode="fan_in"))
+    model.checkpoint_mode = args.checkpoint_mode
     model = model.to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     trainer = DataParallelTrainer(model, opt)
@@ -199,7 +202,8 @@ def main():
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DC3D st_dram_ref (norm={args.norm}, checkpoint_layers as shipped) "
+            "config": {"workload": f"DC3D st_dram_ref (norm={args.norm}, checkpoint_layers as shipped, honoured as "
+                                   f"'{model.checkpoint_mode}') "
                                    f"fwd+loss+bwd+Adam, {args.chunks}x1x{args.size}^3 chunks per GPU, "
                                    f"micro-batch {args.micro}, fp32",
                        "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,

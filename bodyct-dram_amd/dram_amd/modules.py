@@ -41,13 +41,22 @@ class _NormMixin:
 class HipBatchNorm3d(nn.BatchNorm3d, _NormMixin):
     """nn.BatchNorm3d ("bn", "bnt", "bntna" of normal_wrapper, parts.py:18-25)."""
 
+    # number of times the running statistics absorb this batch (2 inside a block that the
+    # reference would run twice per step through torch.utils.checkpoint; models.DC3D._run)
+    stat_updates = 1
+
     def forward(self, x, relu=False):
         self._check_input_dim(x)
-        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward
+        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward, repeated stat_updates
+        # times with the same batch statistics: r <- (1-m) r + m b twice == once with 1-(1-m)^2
         eaf = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
-            eaf = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+            keep = 1.0
+            for _ in range(max(1, int(self.stat_updates))):
+                self.num_batches_tracked.add_(1)
+                m = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+                keep *= (1.0 - m)
+            eaf = 1.0 - keep
         use_batch = self.training or (self.running_mean is None and self.running_var is None)
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None

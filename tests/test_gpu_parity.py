@@ -449,3 +449,25 @@ def test_dc3d_full_golden(golden_dir):
     for k, v in _sub(z, "full_bn/sd_after/").items():
         check(model.state_dict()[k].double(), v.astype(np.float64), f"full buffer {k}")
     assert int(model.state_dict()["ds_modules.1.conv_blocks.0.1.num_batches_tracked"]) == 2
+
+
+def test_checkpoint_modes_agree(golden_dir):
+    """DC3D.checkpoint_mode 'stats' (no recomputation, BatchNorm buffers updated twice) and
+    'recompute' (torch.utils.checkpoint like the reference) give the same step."""
+    import models
+    z = np.load(os.path.join(golden_dir, "dc3d_slim.npz"))
+    res = {}
+    for mode in ("stats", "recompute"):
+        model = models.DC3D(**SLIM)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in _sub(z, "slim_bn/sd/").items()})
+        model.checkpoint_mode = mode
+        model = model.to(DEV).train()
+        d0, _ = model(dev(torch.from_numpy(z["slim_bn/x"])))
+        (d0 * dev(torch.from_numpy(z["slim_bn/gout"]))).sum().backward()
+        res[mode] = (d0.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters()},
+                     {k: v.cpu().double() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
+    assert torch.equal(res["stats"][0], res["recompute"][0])
+    for k in res["stats"][1]:
+        assert torch.equal(res["stats"][1][k], res["recompute"][1][k]), k     # same kernels, same inputs: bit-exact
+    for k in res["stats"][2]:
+        check(res["stats"][2][k], res["recompute"][2][k], f"buffer {k}", tol=1e-6)
