@@ -342,6 +342,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     float rdy[DYQ];
     float rx[CI_B][NQ];
 
+    // One buffer descriptor per tensor and sample (num_records = the sample's bytes); the channel plane
+    // is folded into the per-lane byte offset, which runs from channel to channel with one VALU add.
+    // No per-channel condition exists: a channel beyond the tensor's last one is an offset beyond
+    // num_records and the hardware returns 0, and an out-of-volume halo lane keeps the OOB offset (its
+    // increment is 0).  (Per-plane descriptors / scalar offsets / per-channel predicates are all loop
+    // invariant, get hoisted out of the box loop and need >100 SGPRs: hipcc then spills them through
+    // v_writelane/v_readlane, ~700 extra VALU instructions per box, measured.)
+    const unsigned S4 = 4u * (unsigned)S, S24 = 4u * (unsigned)S2;
+    // which tensor(s) this block's CI_B channels come from: 0 = x1 only, 1 = x2 only, 2 = straddles both
+    const int src_mode = (a.src.p2 == nullptr || ci0 + CI_B <= a.src.C1) ? 0 : (ci0 >= a.src.C1 ? 1 : 2);
     auto load_box = [&](int box) {
         int bb = box;
         const int bx = bb % a.nbx; bb /= a.nbx;
@@ -349,41 +359,59 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
         const int bz = bb % a.nbz;
         const int n = bb / a.nbz;
         const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-        {   // dY[CO_B][VOX]: one descriptor per sample, channel row as a scalar offset
+        {   // dY[CO_B][VOX]
             const int gx = x0 + svx, gy = y0 + svy, gz = z0 + svz;
             const bool vok = gx < W && gy < H && gz < D;
-            const unsigned voff = vok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
             const __amdgpu_buffer_rsrc_t srd =
-                make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), 4u * (unsigned)a.Cout * (unsigned)S);
+                make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), (unsigned)a.Cout * S4);
+            unsigned run = vok ? 4u * (unsigned)((gz * H + gy) * W + gx) + (unsigned)(co0 + co_st) * S4 : OOB;
+            const unsigned inc = vok ? (unsigned)RPP * S4 : 0u;
 #pragma unroll
             for (int q = 0; q < DYQ; ++q) {
-                const int co = co0 + co_st + RPP * q;            // wave-uniform
-                const bool cok = co < a.Cout;
-                rdy[q] = buf_load(srd, cok ? voff : OOB, cok ? 4u * (unsigned)co * (unsigned)S : 0u);
+                rdy[q] = buf_load(srd, run, 0);
+                run += inc;
             }
         }
-        {   // X[CI_B][halo]: one descriptor per channel plane (0 records beyond Cin -> zeros)
-            unsigned off1[NQ], off2[NQ];
+        {   // X[CI_B][halo]
+            unsigned run1[NQ], run2[NQ], inc1[NQ], inc2[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int e = tid + T * q;
                 const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
                 const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
                 const bool ok = (e < HV) && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
-                off1[q] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
-                off2[q] = ok ? 4u * (unsigned)(((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
+                run1[q] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) + (unsigned)ci0 * S4 : OOB;
+                // (ci0 - C1) may be negative: the unsigned offset wraps and is out of range until ci reaches C1
+                run2[q] = ok ? 4u * (unsigned)(((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox) +
+                                   (unsigned)(ci0 - a.src.C1) * S24 : OOB;
+                inc1[q] = ok ? S4 : 0u;
+                inc2[q] = ok ? S24 : 0u;
             }
-            const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
-            const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
+            const __amdgpu_buffer_rsrc_t srd1 =
+                make_rsrc(uniform_ptr(a.src.p1 + (size_t)n * a.src.C1 * S), (unsigned)a.src.C1 * S4);
+            if (src_mode == 0) {
 #pragma unroll
-            for (int c = 0; c < CI_B; ++c) {
-                const int ci = ci0 + c;
-                const bool first = ci < a.src.C1;
-                const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
-                const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;
-                const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(plane), bytes);
+                for (int c = 0; c < CI_B; ++c)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) rx[c][q] = buf_load(srd, first ? off1[q] : off2[q], 0);
+                    for (int q = 0; q < NQ; ++q) { rx[c][q] = buf_load(srd1, run1[q], 0); run1[q] += inc1[q]; }
+            } else {
+                const __amdgpu_buffer_rsrc_t srd2 =
+                    make_rsrc(uniform_ptr(a.src.p2 + (size_t)n * a.src.C2 * S2), (unsigned)a.src.C2 * S24);
+                if (src_mode == 1) {
+#pragma unroll
+                    for (int c = 0; c < CI_B; ++c)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) { rx[c][q] = buf_load(srd2, run2[q], 0); run2[q] += inc2[q]; }
+                } else {   // rare: the tile straddles the two tensors -> load from both, one of them returns 0
+#pragma unroll
+                    for (int c = 0; c < CI_B; ++c)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            rx[c][q] = buf_load(srd1, run1[q], 0) + buf_load(srd2, run2[q], 0);
+                            run1[q] += inc1[q];
+                            run2[q] += inc2[q];
+                        }
+                }
             }
         }
     };
@@ -579,8 +607,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
 
 static int check_conv_shape(const char* who, int N, int Cin, int Cout, int D, int H, int W) {
     DRAM_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "%s: non-positive dimension", who);
-    DRAM_REQUIRE((int64_t)D * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < 0x3fffffffLL,
-                 "%s: one sample exceeds 2^30 elements (32-bit buffer descriptors)", who);
+    DRAM_REQUIRE((int64_t)D * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < 0x1fffffffLL,
+                 "%s: one sample exceeds 2^29 elements (2 GiB; 32-bit buffer offsets with an out-of-range sentinel)", who);
     return DRAM_OK;
 }
 
