@@ -136,16 +136,23 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
     }
 }
 
-// out[j] = sum over `count` partial vectors of length L (fp64 accumulate, fixed order)
-__global__ void sum_partials_kernel(const float* __restrict__ part, int count, int L, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int Cin, int Cout) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= L) return;
+// out[j] = sum over `count` partial vectors of length L: one 256-thread block per j, fp64, fixed order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int count, int L,
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int Cin,
+                                                           int Cout) {
+    __shared__ double red[4];
+    const int j = blockIdx.x;
     double s = 0.0;
-    for (int p = 0; p < count; ++p) s += part[(size_t)p * L + j];
-    const int o = j / (Cin + 1), c = j % (Cin + 1);
-    if (c < Cin) { if (dw) dw[(size_t)o * Cin + c] = (float)s; }
-    else if (dbias) dbias[o] = (float)s;
+    for (int p = threadIdx.x; p < count; p += 256) s += part[(size_t)p * L + j];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = red[0] + red[1] + red[2] + red[3];
+        const int o = j / (Cin + 1), c = j % (Cin + 1);
+        if (c < Cin) { if (dw) dw[(size_t)o * Cin + c] = (float)s; }
+        else if (dbias) dbias[o] = (float)s;
+    }
 }
 
 // ---------------------------------------------------------------- per-channel sum (conv bias gradient)
@@ -280,7 +287,7 @@ extern "C" int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* 
         float* part = (float*)ws;
         hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk);
         const int L = Cout * (Cin + 1);
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 256)), dim3(256), 0, st, part, N * nblk, L, dw, dbias, Cin, Cout);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(L), dim3(256), 0, st, part, N * nblk, L, dw, dbias, Cin, Cout);
     }
     return check_launch("conv3d_k1_bwd");
 }

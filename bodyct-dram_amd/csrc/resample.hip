@@ -71,9 +71,11 @@ __device__ __forceinline__ void src_index(const Axis& a, int o, int& i0, int& i1
     l0 = 1.f - l1;
 }
 
+// one thread per output voxel; the source indices / weights are computed once and reused for CPT
+// consecutive (n,c) planes (the index arithmetic, not the 8 loads, dominates a plane-per-thread version)
+constexpr int TRI_CPT = 8;
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            Axis az, Axis ay, Axis ax) {
-    const int64_t plane = blockIdx.y;
+                                                            Axis az, Axis ay, Axis ax, int planes) {
     const int So = az.out * ay.out * ax.out;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= So) return;
@@ -83,12 +85,22 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
     src_index(az, zo, z0, z1, a0, a1);
     src_index(ay, yo, y0, y1, b0, b1);
     src_index(ax, xo, x0, x1, c0, c1);
-    const float* p = x + plane * ((int64_t)az.in * ay.in * ax.in);
     const int H = ay.in, W = ax.in;
-    auto at = [&](int z, int yy, int xx) { return p[((int64_t)z * H + yy) * W + xx]; };
-    const float v = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
-                    a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
-    y[plane * (int64_t)So + e] = v;
+    const int Si = az.in * H * W;
+    const int o000 = (z0 * H + y0) * W + x0, o001 = (z0 * H + y0) * W + x1;
+    const int o010 = (z0 * H + y1) * W + x0, o011 = (z0 * H + y1) * W + x1;
+    const int o100 = (z1 * H + y0) * W + x0, o101 = (z1 * H + y0) * W + x1;
+    const int o110 = (z1 * H + y1) * W + x0, o111 = (z1 * H + y1) * W + x1;
+    const int p0 = blockIdx.y * TRI_CPT;
+#pragma unroll
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        const float* p = x + (int64_t)plane * Si;
+        const float v = a0 * (b0 * (c0 * p[o000] + c1 * p[o001]) + b1 * (c0 * p[o010] + c1 * p[o011])) +
+                        a1 * (b0 * (c0 * p[o100] + c1 * p[o101]) + b1 * (c0 * p[o110] + c1 * p[o111]));
+        y[(int64_t)plane * So + e] = v;
+    }
 }
 
 // Adjoint in gather form.  For input index i the outputs that touch it form the contiguous range
@@ -113,8 +125,67 @@ __device__ __forceinline__ float touch_weight(const Axis& a, int o, int i) {
     return w;
 }
 
+// per-axis taps of one input index: outputs lo..lo+MAXT-1 with their weights (0 where they do not touch it)
+constexpr int MAXT = 6;
+struct Taps {
+    int lo, n;
+    float w[MAXT];
+};
+__device__ __forceinline__ Taps axis_taps(const Axis& a, int i) {
+    Taps t;
+    int lo, hi;
+    touch_range(a, i, lo, hi);
+    // shrink to the outputs that really touch input i
+    while (lo <= hi && touch_weight(a, lo, i) == 0.f) ++lo;
+    while (hi >= lo && touch_weight(a, hi, i) == 0.f) --hi;
+    t.lo = lo;
+    t.n = hi - lo + 1;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) t.w[k] = (k < t.n) ? touch_weight(a, lo + k, i) : 0.f;
+    return t;
+}
+
+// host-side bound on the taps per input index, so that MAXT is never exceeded silently
+static int max_taps_host(int in, int out) {
+    if (out <= 1 || in <= 1) return out;
+    // outputs o with floor(o*s) in {i-1, i}: at most ceil(2/s)+1
+    const double s = (double)(in - 1) / (double)(out - 1);
+    return (int)(2.0 / s) + 2;
+}
+
 __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                            Axis az, Axis ay, Axis ax) {
+                                                            Axis az, Axis ay, Axis ax, int planes) {
+    const int S = az.in * ay.in * ax.in;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    const int xi = e % ax.in, yi = (e / ax.in) % ay.in, zi = e / (ax.in * ay.in);
+    const Taps tz = axis_taps(az, zi), ty = axis_taps(ay, yi), tx = axis_taps(ax, xi);
+    const int So = az.out * ay.out * ax.out;
+    const int p0 = blockIdx.y * TRI_CPT;
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        const float* p = dy + (int64_t)plane * So;
+        float acc = 0.f;
+        for (int kz = 0; kz < tz.n; ++kz) {
+            float zacc = 0.f;
+            for (int ky = 0; ky < ty.n; ++ky) {
+                const float* row = p + ((int64_t)(tz.lo + kz) * ay.out + ty.lo + ky) * ax.out + tx.lo;
+                float racc = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < MAXT; ++kx)
+                    if (kx < tx.n) racc += tx.w[kx] * row[kx];
+                zacc += ty.w[ky] * racc;
+            }
+            acc += tz.w[kz] * zacc;
+        }
+        dx[(int64_t)plane * S + e] = acc;
+    }
+}
+
+// general fallback (any magnification): plane per blockIdx.y, weights recomputed inside the loops
+__global__ __launch_bounds__(256) void trilinear_bwd_general_kernel(const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, Axis az, Axis ay, Axis ax) {
     const int64_t plane = blockIdx.y;
     const int S = az.in * ay.in * ax.in;
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -134,10 +205,7 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
             if (wy == 0.f) continue;
             const float* row = p + ((int64_t)zo * ay.out + yo) * ax.out;
             float racc = 0.f;
-            for (int xo = xl; xo <= xh; ++xo) {
-                const float wx = touch_weight(ax, xo, xi);
-                racc += wx * row[xo];
-            }
+            for (int xo = xl; xo <= xh; ++xo) racc += touch_weight(ax, xo, xi) * row[xo];
             acc += wz * wy * racc;
         }
     }
@@ -236,9 +304,9 @@ extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, i
     DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_fwd: bad sizes");
     int rc = check_planes("upsample_trilinear_ac_fwd", (int64_t)N * C, (int64_t)Do * Ho * Wo);
     if (rc) return rc;
-    dim3 grid(cdiv(Do * Ho * Wo, 256), N * C);
+    dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
     hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
-                       make_axis(H, Ho), make_axis(W, Wo));
+                       make_axis(H, Ho), make_axis(W, Wo), N * C);
     return check_launch("upsample_trilinear_ac_fwd");
 }
 
@@ -248,9 +316,15 @@ extern "C" int dram_upsample_trilinear_ac_bwd(const float* dy, float* dx, int N,
     DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_bwd: bad sizes");
     int rc = check_planes("upsample_trilinear_ac_bwd", (int64_t)N * C, (int64_t)D * H * W);
     if (rc) return rc;
-    dim3 grid(cdiv(D * H * W, 256), N * C);
-    hipLaunchKernelGGL(trilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, make_axis(D, Do),
-                       make_axis(H, Ho), make_axis(W, Wo));
+    if (max_taps_host(D, Do) <= MAXT && max_taps_host(H, Ho) <= MAXT && max_taps_host(W, Wo) <= MAXT) {
+        dim3 grid(cdiv(D * H * W, 256), cdiv(N * C, TRI_CPT));
+        hipLaunchKernelGGL(trilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, make_axis(D, Do),
+                           make_axis(H, Ho), make_axis(W, Wo), N * C);
+    } else {   // magnification above ~2.5x on some axis
+        dim3 grid(cdiv(D * H * W, 256), N * C);
+        hipLaunchKernelGGL(trilinear_bwd_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx,
+                           make_axis(D, Do), make_axis(H, Ho), make_axis(W, Wo));
+    }
     return check_launch("upsample_trilinear_ac_bwd");
 }
 
