@@ -48,7 +48,7 @@ struct ConvArgs {
     const float* wt;    // [27][Cin][Cout]
     const float* bias;  // [Cout] or null
     int N, Cin, Cout, D, H, W;
-    int nbx, nby, nbz;
+    int nbx, nby, nbz, co_tiles;
 };
 
 constexpr int KC = 4;  // input channels per LDS stage
@@ -87,6 +87,16 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2): hardware block b
+// runs on XCD b % 8.  Map it to a logical work item so that every XCD walks a contiguous range of
+// items: neighbouring boxes (shared halos) and the tiles that share a box then hit the same L2.
+// Bijective for any n; placement is a speed matter only.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n / 8, r = n % 8;
+    const int xcd = b % 8, idx = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // Software pipeline (one barrier per K chunk): while the MFMAs of chunk c run out of LDS stage
 // c&1, the global loads of chunk c+1 are in flight into registers; they are written to the other
 // stage after the MFMAs and become visible at the barrier.  Inside a chunk the LDS operand reads
@@ -104,13 +114,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, co tile), co tile fastest
+    const int co0 = (b % a.co_tiles) * COB; b /= a.co_tiles;
     const int bx = b % a.nbx; b /= a.nbx;
     const int by = b % a.nby; b /= a.nby;
     const int bz = b % a.nbz;
     const int n = b / a.nbz;
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-    const int co0 = blockIdx.y * COB;
     const int D = a.D, H = a.H, W = a.W;
     const int S = D * H * W;
     const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave % COS, wci = wave / COS;   // this wave's (co, ci) sub-tile
-    int b = blockIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (split, co tile, ci tile), ci tile fastest
     const int ci_t = b % a.ci_tiles; b /= a.ci_tiles;
     const int co_t = b % a.co_tiles;
     const int sp = b / a.co_tiles;
@@ -523,8 +533,13 @@ static int launch_fwd_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
         }
         attr_done = true;
     }
-    dim3 grid(nblk, cdiv(a.Cout, 32 * COT));
-    hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, COT>), grid, dim3(256), G::LDS_BYTES, st, a);
+    a.co_tiles = cdiv(a.Cout, 32 * COT);
+    const int64_t total = (int64_t)nblk * a.co_tiles;
+    if (total > 0x7fffffffLL) {
+        set_error("conv3d_k3_fwd: grid too large");
+        return DRAM_EINVAL;
+    }
+    hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, COT>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_fwd");
 }
 
