@@ -1,0 +1,227 @@
+// Per-lobe whole-scan inference helpers, gfx950.
+//
+// Device-side restatement of the data movement around the model call in the reference's
+// `LesionSegChunkTrain.evaluate_scan` (dram/job_runner.py:729-770) and of the thresholding in
+// `LesionSegTest.run` (dram/job_runner.py:1003-1005, `binary_cam` dram/utils.py:226-242):
+//   label_bboxes      bounding box of every lobe label            (find_crops, utils.py:244-254)
+//   lobe_chunks       crop + mask outside lobe to -2048 + window to [0,1] + resample to R^3
+//                     (job_runner.py:733-737, data_transforms.py:37-54, Resample 'fixed_size')
+//   lobe_paste        sigmoid -> trilinear (align_corners) resize to the crop size -> paste where
+//                     lobe == label (job_runner.py:765-770)
+//   hist256 / threshold: 8-bit histogram inside the lungs for Otsu, mask = htp > th
+// All HBM-bound gathers/streams; one thread per output voxel.  The scan (int16) and the lobe label
+// map (uint8) stay resident in HBM; nothing goes back to the host except 5 boxes and 256 counts.
+//
+// Resampling grid: the reference resamples with SimpleITK (absent here: parity unpinned); this build
+// defines the crop -> R^3 resampling as trilinear with align_corners=True, the same operator the
+// reference itself uses for the way back (F.interpolate(..., align_corners=True), job_runner.py:767).
+#include "common.h"
+
+namespace dram {
+
+// boxes[l*6 + {0,1,2}] = min z,y,x ; {3,4,5} = max z,y,x (inclusive); min > max when the label is absent
+__global__ void bbox_init_kernel(int* boxes, int nlabels) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nlabels * 6) boxes[i] = (i % 6) < 3 ? 0x7fffffff : -1;
+}
+
+__global__ __launch_bounds__(256) void label_bboxes_kernel(const uint8_t* __restrict__ lobe, int* __restrict__ boxes,
+                                                           int nlabels, int D, int H, int W) {
+    // one block per (z, y-strip); per-wave reduction of x extents, then integer atomics (deterministic)
+    const int z = blockIdx.y;
+    const int y = blockIdx.x;
+    const uint8_t* row = lobe + ((size_t)z * H + y) * W;
+    for (int l = 1; l <= nlabels; ++l) {
+        int xmin = 0x7fffffff, xmax = -1;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            if (row[x] == l) { xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(xmin, o, 64), b = __shfl_xor(xmax, o, 64);
+            xmin = a < xmin ? a : xmin;
+            xmax = b > xmax ? b : xmax;
+        }
+        if ((threadIdx.x & 63) == 0 && xmax >= 0) {
+            int* bx = boxes + (l - 1) * 6;
+            atomicMin(bx + 0, z); atomicMin(bx + 1, y); atomicMin(bx + 2, xmin);
+            atomicMax(bx + 3, z); atomicMax(bx + 4, y); atomicMax(bx + 5, xmax);
+        }
+    }
+}
+
+struct Chunk {   // crop window [z0,z0+dz) x [y0,y0+dy) x [x0,x0+dx) of lobe `label`
+    int z0, y0, x0, dz, dy, dx, label, pad;
+};
+constexpr int MAX_CHUNKS = 8;
+struct ChunkList {
+    Chunk c[MAX_CHUNKS];
+};
+
+__device__ __forceinline__ void ac_index(int in, int out, int o, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;   // ATen area_pixel_compute_scale
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// out[l][R][R][R]: windowed, lobe-masked crop resampled to R^3
+__global__ __launch_bounds__(256) void lobe_chunks_kernel(const int16_t* __restrict__ scan,
+                                                          const uint8_t* __restrict__ lobe, float* __restrict__ out,
+                                                          ChunkList cl, int H, int W, int R, float wmin, float wmax) {
+    const int l = blockIdx.y;
+    const Chunk c = cl.c[l];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * R * R) return;
+    const int xo = e % R, yo = (e / R) % R, zo = e / (R * R);
+    int z0, z1, y0, y1, x0, x1;
+    float a0, a1, b0, b1, c0, c1;
+    ac_index(c.dz, R, zo, z0, z1, a0, a1);
+    ac_index(c.dy, R, yo, y0, y1, b0, b1);
+    ac_index(c.dx, R, xo, x0, x1, c0, c1);
+    const float inv = 1.f / (wmax - wmin);
+    auto at = [&](int z, int y, int x) -> float {
+        const size_t o = ((size_t)(c.z0 + z) * H + (c.y0 + y)) * W + (c.x0 + x);
+        if (lobe[o] != c.label) return 0.f;                       // -2048 HU clips to the window minimum -> 0
+        float v = (float)scan[o];
+        v = fminf(fmaxf(v, wmin), wmax);
+        return (v - wmin) * inv;                                  // windowing(), utils.py:189-198, to_span (0,1)
+    };
+    const float v = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+                    a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+    out[(size_t)l * R * R * R + e] = v;
+}
+
+// htp[v] = trilinear_ac(sigmoid(dense_l))(v) for every voxel v of the crop with lobe == label
+__global__ __launch_bounds__(256) void lobe_paste_kernel(const float* __restrict__ dense,
+                                                         const uint8_t* __restrict__ lobe, float* __restrict__ htp,
+                                                         ChunkList cl, int H, int W, int R) {
+    const int l = blockIdx.y;
+    const Chunk c = cl.c[l];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= c.dz * c.dy * c.dx) return;
+    const int x = e % c.dx, y = (e / c.dx) % c.dy, z = e / (c.dx * c.dy);
+    const size_t o = ((size_t)(c.z0 + z) * H + (c.y0 + y)) * W + (c.x0 + x);
+    if (lobe[o] != c.label) return;
+    int z0, z1, y0, y1, x0, x1;
+    float a0, a1, b0, b1, c0, c1;
+    ac_index(R, c.dz, z, z0, z1, a0, a1);
+    ac_index(R, c.dy, y, y0, y1, b0, b1);
+    ac_index(R, c.dx, x, x0, x1, c0, c1);
+    const float* p = dense + (size_t)l * R * R * R;
+    auto at = [&](int zz, int yy, int xx) -> float {
+        const float d = p[((size_t)zz * R + yy) * R + xx];
+        return 1.f / (1.f + expf(-d));                            // F.sigmoid before the resize, job_runner.py:765
+    };
+    htp[o] = a0 * (b0 * (c0 * at(z0, y0, x0) + c1 * at(z0, y0, x1)) + b1 * (c0 * at(z0, y1, x0) + c1 * at(z0, y1, x1))) +
+             a1 * (b0 * (c0 * at(z1, y0, x0) + c1 * at(z1, y0, x1)) + b1 * (c0 * at(z1, y1, x0) + c1 * at(z1, y1, x1)));
+}
+
+// hist[b] = #{v : lobe[v] > 0, uint8(clip(htp[v],0,1)*255) == b}; also sum of htp inside the lungs (fp64) and the count
+__global__ __launch_bounds__(256) void lung_hist_kernel(const float* __restrict__ htp, const uint8_t* __restrict__ lobe,
+                                                        unsigned long long* __restrict__ hist, double* __restrict__ sum,
+                                                        size_t n) {
+    __shared__ unsigned lh[256];
+    __shared__ double lsum[4];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if (lobe[i] > 0) {
+            const float v = htp[i];
+            const float w = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+            atomicAdd(&lh[(int)w], 1u);
+            s += (double)v;
+        }
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) lsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(sum, lsum[0] + lsum[1] + lsum[2] + lsum[3]);
+}
+
+__global__ void threshold_kernel(const float* __restrict__ htp, uint8_t* __restrict__ mask, float th, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) mask[i] = htp[i] > th ? 1 : 0;
+}
+
+}  // namespace dram
+
+using namespace dram;
+
+extern "C" int dram_label_bboxes(const uint8_t* lobe, int* boxes, int nlabels, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(lobe && boxes, "label_bboxes: null pointer");
+    DRAM_REQUIRE(nlabels > 0 && nlabels <= 255 && D > 0 && H > 0 && W > 0 && D <= 65535, "label_bboxes: bad dimensions");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(cdiv(nlabels * 6, 64)), dim3(64), 0, st, boxes, nlabels);
+    hipLaunchKernelGGL(label_bboxes_kernel, dim3(H, D), dim3(256), 0, st, lobe, boxes, nlabels, D, H, W);
+    return check_launch("label_bboxes");
+}
+
+static int fill_chunks(const char* who, ChunkList& cl, const int* chunks, int L, int D, int H, int W) {
+    DRAM_REQUIRE(chunks && L > 0 && L <= MAX_CHUNKS, "%s: between 1 and %d chunks", who, MAX_CHUNKS);
+    for (int l = 0; l < L; ++l) {
+        Chunk& c = cl.c[l];
+        c.z0 = chunks[l * 7 + 0]; c.y0 = chunks[l * 7 + 1]; c.x0 = chunks[l * 7 + 2];
+        c.dz = chunks[l * 7 + 3]; c.dy = chunks[l * 7 + 4]; c.dx = chunks[l * 7 + 5];
+        c.label = chunks[l * 7 + 6]; c.pad = 0;
+        DRAM_REQUIRE(c.z0 >= 0 && c.y0 >= 0 && c.x0 >= 0 && c.dz > 0 && c.dy > 0 && c.dx > 0 && c.z0 + c.dz <= D &&
+                         c.y0 + c.dy <= H && c.x0 + c.dx <= W, "%s: chunk %d outside the volume", who, l);
+    }
+    return DRAM_OK;
+}
+
+// chunks: host array of L x {z0,y0,x0,dz,dy,dx,label}
+extern "C" int dram_lobe_chunks(const int16_t* scan, const uint8_t* lobe, float* out, const int* chunks, int L, int D,
+                                int H, int W, int R, float wmin, float wmax, void* stream) {
+    DRAM_REQUIRE(scan && lobe && out, "lobe_chunks: null pointer");
+    DRAM_REQUIRE(R > 0 && wmax > wmin, "lobe_chunks: bad resample size or window");
+    ChunkList cl;
+    int rc = fill_chunks("lobe_chunks", cl, chunks, L, D, H, W);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lobe_chunks_kernel, dim3(cdiv(R * R * R, 256), L), dim3(256), 0, (hipStream_t)stream, scan, lobe,
+                       out, cl, H, W, R, wmin, wmax);
+    return check_launch("lobe_chunks");
+}
+
+extern "C" int dram_lobe_paste(const float* dense, const uint8_t* lobe, float* htp, const int* chunks, int L, int D,
+                               int H, int W, int R, void* stream) {
+    DRAM_REQUIRE(dense && lobe && htp, "lobe_paste: null pointer");
+    DRAM_REQUIRE(R > 0, "lobe_paste: bad resample size");
+    ChunkList cl;
+    int rc = fill_chunks("lobe_paste", cl, chunks, L, D, H, W);
+    if (rc) return rc;
+    int64_t mx = 0;
+    for (int l = 0; l < L; ++l) {
+        const int64_t v = (int64_t)cl.c[l].dz * cl.c[l].dy * cl.c[l].dx;
+        mx = v > mx ? v : mx;
+    }
+    DRAM_REQUIRE(mx < 0x7fffffffLL, "lobe_paste: chunk too large");
+    hipLaunchKernelGGL(lobe_paste_kernel, dim3((unsigned)cdiv64(mx, 256), L), dim3(256), 0, (hipStream_t)stream, dense,
+                       lobe, htp, cl, H, W, R);
+    return check_launch("lobe_paste");
+}
+
+// hist: 256 x uint64 (zeroed here), sum: 1 x double (zeroed here)
+extern "C" int dram_lung_hist256(const float* htp, const uint8_t* lobe, unsigned long long* hist, double* sum,
+                                 int64_t n, void* stream) {
+    DRAM_REQUIRE(htp && lobe && hist && sum && n > 0, "lung_hist256: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(sum, 0, sizeof(double), st);
+    const unsigned grid = (unsigned)(cdiv64(n, 256 * 16) < 2048 ? cdiv64(n, 256 * 16) : 2048);
+    hipLaunchKernelGGL(lung_hist_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, htp, lobe, hist, sum, (size_t)n);
+    return check_launch("lung_hist256");
+}
+
+extern "C" int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, void* stream) {
+    DRAM_REQUIRE(htp && mask && n > 0, "threshold_mask: bad arguments");
+    const unsigned grid = (unsigned)(cdiv64(n, 256) < 4096 ? cdiv64(n, 256) : 4096);
+    hipLaunchKernelGGL(threshold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, htp, mask, th, (size_t)n);
+    return check_launch("threshold_mask");
+}

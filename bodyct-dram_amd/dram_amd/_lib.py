@@ -43,6 +43,11 @@ SIGNATURES = {
     "dram_masked_mean_ws_bytes": (Z, [I, I, L]),
     "dram_masked_mean_fwd": (I, [P, P, P, P, P, Z, I, I, L, P]),
     "dram_masked_mean_bwd": (I, [P, P, P, P, I, I, L, P]),
+    "dram_label_bboxes": (I, [P, P, I, I, I, I, P]),
+    "dram_lobe_chunks": (I, [P, P, P, P, I, I, I, I, I, F, F, P]),
+    "dram_lobe_paste": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dram_lung_hist256": (I, [P, P, P, P, L, P]),
+    "dram_threshold_mask": (I, [P, P, F, L, P]),
 }
 
 

@@ -1,0 +1,148 @@
+"""Whole-scan, per-lobe inference on the GPU.
+
+Device-resident restatement of the reference's working inference semantics,
+`LesionSegChunkTrain.evaluate_scan` (dram/job_runner.py:720-779): for every lobe label, crop
+its bounding box (+5 mm), mask outside-lobe voxels to -2048 HU, window (-1000,-300) -> [0,1],
+resample to RESAMPLE_SIZE (80^3), run the model, sigmoid, resize back to the crop size and paste
+where the lobe is; then the thresholding of `LesionSegTest.run` (job_runner.py:1003-1005):
+Otsu on the 8-bit heat map inside the lungs (`binary_cam`, dram/utils.py:226-242), mask = htp > th.
+
+Differences from the reference, on purpose: the <= 5 lobes go through the model as ONE batch of
+N = #lobes chunks; the scan and the label map are uploaded once and every step runs on the device
+(the reference round-trips each lobe through numpy and SimpleITK); the crop -> 80^3 resampling is
+trilinear with align_corners=True (SimpleITK is not available here: that step's parity is unpinned;
+the way back uses the same operator as the reference's F.interpolate(align_corners=True)).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+
+# IntRegLoss.ctss_ratio_map / ratio_to_label (dram/metrics.py:76-83, 108-114)
+CTSS_RATIO_MAP = {0: (0.0, 0.001), 1: (0.001, 0.01), 2: (0.01, 0.05), 3: (0.05, 0.35), 4: (0.35, 0.5), 5: (0.5, 1.00001)}
+
+
+def ratio_to_label(ratio):
+    return [k for k, (lo, hi) in CTSS_RATIO_MAP.items() if lo <= ratio < hi][0]
+
+
+def otsu_threshold_from_hist(hist):
+    """skimage.filters.threshold_otsu on a uint8 image, restated from its published algorithm
+    (maximise the between-class variance over the histogram of the occupied value range) and
+    evaluated on the 256-bin histogram.  Returns the threshold in 0..255."""
+    hist = np.asarray(hist, dtype=np.float64)
+    nz = np.nonzero(hist)[0]
+    lo, hi = int(nz[0]), int(nz[-1])
+    h = hist[lo:hi + 1]
+    centers = np.arange(lo, hi + 1, dtype=np.float64)
+    w1 = np.cumsum(h)
+    w2 = np.cumsum(h[::-1])[::-1]
+    m1 = np.cumsum(h * centers) / w1
+    m2 = (np.cumsum((h * centers)[::-1]) / w2[::-1])[::-1]
+    var12 = w1[:-1] * w2[1:] * (m1[:-1] - m2[1:]) ** 2
+    return float(centers[int(np.argmax(var12))])
+
+
+def binary_cam_threshold(hist, scaler=1.0):
+    """`binary_cam` (dram/utils.py:226-242) on the 8-bit histogram: returns th / 255."""
+    hist = np.asarray(hist)
+    if np.count_nonzero(hist) < 2:                      # only one colour
+        return float(np.nonzero(hist)[0][0]) / 255.0
+    return min(otsu_threshold_from_hist(hist) * scaler, 255.0) / 255.0
+
+
+class LobeInference:
+    """model: a models.DC3D on the GPU.  run(scan_i16, lobe_u8, spacing) -> dict."""
+
+    def __init__(self, model, resample_size=80, window=(-1000.0, -300.0), border_mm=5.0, max_labels=5):
+        self.model, self.R, self.window, self.border, self.max_labels = model, int(resample_size), window, border_mm, max_labels
+
+    @torch.no_grad()
+    def run(self, scan, lobe, spacing):
+        dev = next(self.model.parameters()).device
+        scan = torch.as_tensor(scan).to(device=dev, dtype=torch.int16).contiguous()
+        lobe = torch.as_tensor(lobe).to(device=dev, dtype=torch.uint8).contiguous()
+        if scan.dim() != 3 or scan.shape != lobe.shape:
+            raise ValueError("scan and lobe must be [D,H,W] arrays of the same shape")
+        D, H, W = scan.shape
+        st = torch.cuda.current_stream().cuda_stream
+        boxes = torch.empty(self.max_labels * 6, dtype=torch.int32, device=dev)
+        call("dram_label_bboxes", lobe.data_ptr(), boxes.data_ptr(), self.max_labels, D, H, W, st)
+        boxes = boxes.cpu().numpy().reshape(self.max_labels, 6)            # the only sync before the model: 30 ints
+        chunks = []
+        for label in range(1, self.max_labels + 1):
+            lo, hi = boxes[label - 1, :3], boxes[label - 1, 3:]
+            if hi[0] < lo[0]:
+                continue                                                     # label absent (np.unique(lobe)[1:])
+            start, stop = [], []
+            for ax, (l, h, size, sp) in enumerate(zip(lo, hi, (D, H, W), spacing)):   # find_crops, utils.py:244-254
+                pad = int(math.ceil(self.border / sp)) if self.border > 0 else 0
+                start.append(max(0, int(l) - pad))
+                stop.append(min(size, int(h) + 1 + pad))
+            chunks.append(start + [b - a for a, b in zip(start, stop)] + [label])
+        htp = torch.zeros((D, H, W), dtype=torch.float32, device=dev)
+        if not chunks:
+            return {"htp": htp, "mask": torch.zeros((D, H, W), dtype=torch.uint8, device=dev), "threshold": 0.0,
+                    "lesion_ratio": 0.0, "ctss": 0, "chunks": []}
+        L, R = len(chunks), self.R
+        carr = (ctypes.c_int * (7 * L))(*[v for c in chunks for v in c])
+        x = torch.empty((L, 1, R, R, R), dtype=torch.float32, device=dev)
+        call("dram_lobe_chunks", scan.data_ptr(), lobe.data_ptr(), x.data_ptr(), carr, L, D, H, W, R,
+             float(self.window[0]), float(self.window[1]), st)
+        was_training = self.model.training
+        self.model.eval()
+        dense, _ = self.model(x, None)                                       # one batch of L lobe chunks
+        self.model.train(was_training)
+        call("dram_lobe_paste", dense.contiguous().data_ptr(), lobe.data_ptr(), htp.data_ptr(), carr, L, D, H, W, R, st)
+        hist = torch.empty(256, dtype=torch.int64, device=dev)
+        ssum = torch.empty(1, dtype=torch.float64, device=dev)
+        call("dram_lung_hist256", htp.data_ptr(), lobe.data_ptr(), hist.data_ptr(), ssum.data_ptr(), htp.numel(), st)
+        hist_h = hist.cpu().numpy()
+        n_lung = int(hist_h.sum())
+        th = binary_cam_threshold(hist_h)
+        mask = torch.empty((D, H, W), dtype=torch.uint8, device=dev)
+        call("dram_threshold_mask", htp.data_ptr(), mask.data_ptr(), float(th), htp.numel(), st)
+        ratio = float(ssum.item()) / max(n_lung, 1)                          # (htp * (lobe>0)).sum() / (lobe>0).sum()
+        return {"htp": htp, "mask": mask, "threshold": th, "lesion_ratio": ratio, "ctss": ratio_to_label(ratio),
+                "chunks": chunks, "input": x}
+
+
+def dice(predict, target, smooth=1e-5):
+    """dram/utils.py:444-446."""
+    predict, target = np.asarray(predict) > 0, np.asarray(target) > 0
+    inter = np.logical_and(predict, target).sum()
+    return (2.0 * inter + smooth) / (predict.sum() + target.sum() + smooth)
+
+
+def synthetic_ct(shape=(300, 512, 512), spacing=(1.0, 0.7, 0.7), seed=7, n_lesions=20):
+    """air -1000, lung parenchyma N(-850,60^2) inside 5 disjoint
+    ellipsoid "lobes" labelled 1-5, spherical lesions N(-300,80^2) r in [5,20] voxels, body +40."""
+    rng = np.random.default_rng(seed)
+    D, H, W = shape
+    scan = np.full(shape, 40, dtype=np.int16)
+    lobe = np.zeros(shape, dtype=np.uint8)
+    zz, yy, xx = np.meshgrid(np.arange(D, dtype=np.float32), np.arange(H, dtype=np.float32),
+                             np.arange(W, dtype=np.float32), indexing="ij", sparse=True)
+    centres = [(0.30, 0.45, 0.27), (0.62, 0.50, 0.27), (0.28, 0.45, 0.73), (0.52, 0.36, 0.73), (0.74, 0.60, 0.73)]
+    radii = [(0.17, 0.22, 0.13), (0.17, 0.24, 0.13), (0.13, 0.20, 0.12), (0.10, 0.14, 0.10), (0.13, 0.20, 0.12)]
+    for lab, (c, r) in enumerate(zip(centres, radii), start=1):
+        m = (((zz - c[0] * D) / (r[0] * D)) ** 2 + ((yy - c[1] * H) / (r[1] * H)) ** 2 + ((xx - c[2] * W) / (r[2] * W)) ** 2) < 1.0
+        m &= lobe == 0
+        lobe[m] = lab
+    lung = lobe > 0
+    scan[lung] = rng.normal(-850, 60, size=int(lung.sum())).astype(np.int16)
+    idx = np.argwhere(lung)
+    for _ in range(n_lesions):
+        cz, cy, cx = idx[rng.integers(len(idx))]
+        rad = rng.integers(5, 21) * min(1.0, min(shape) / 300.0)
+        z0, z1 = max(0, int(cz - rad)), min(D, int(cz + rad) + 1)
+        y0, y1 = max(0, int(cy - rad)), min(H, int(cy + rad) + 1)
+        x0, x1 = max(0, int(cx - rad)), min(W, int(cx + rad) + 1)
+        sub = ((zz[z0:z1] - cz) ** 2 + (yy[:, y0:y1] - cy) ** 2 + (xx[:, :, x0:x1] - cx) ** 2) < rad ** 2
+        sub &= lung[z0:z1, y0:y1, x0:x1]
+        scan[z0:z1, y0:y1, x0:x1][sub] = rng.normal(-300, 80, size=int(sub.sum())).astype(np.int16)
+    return scan, lobe, spacing

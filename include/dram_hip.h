@@ -172,6 +172,32 @@ int dram_masked_mean_fwd(const float* x, const float* mask, float* out, float* m
 int dram_masked_mean_bwd(const float* dout, const float* mask, const float* msum, float* dx,
                          int N, int C, int64_t S, void* stream);
 
+/* ---- per-lobe whole-scan inference helpers: LesionSegChunkTrain.evaluate_scan,
+ *      dram/job_runner.py:729-770; thresholding of LesionSegTest.run, job_runner.py:1003-1005 ----
+ * scan: int16 [D,H,W] HU, lobe: uint8 [D,H,W] label map, both resident in HBM.
+ * `chunks` is a HOST array of L x {z0,y0,x0,dz,dy,dx,label} (L <= 8). */
+
+/* boxes[(label-1)*6 + {0,1,2}] = min z,y,x; {3,4,5} = max z,y,x (inclusive); min > max if the label is absent
+ * (find_crops without the border, dram/utils.py:244-254). */
+int dram_label_bboxes(const uint8_t* lobe, int* boxes, int nlabels, int D, int H, int W, void* stream);
+
+/* out[L,1,R,R,R]: crop, set voxels outside the lobe to the window minimum (-2048 HU clips to it), window
+ * [wmin,wmax] -> [0,1] (data_transforms.py:37-54), resample to R^3 (trilinear, align_corners=True). */
+int dram_lobe_chunks(const int16_t* scan, const uint8_t* lobe, float* out, const int* chunks, int L,
+                     int D, int H, int W, int R, float wmin, float wmax, void* stream);
+
+/* htp[v] = resize(sigmoid(dense[l]))(v) for every voxel of chunk l with lobe == label (job_runner.py:765-770). */
+int dram_lobe_paste(const float* dense, const uint8_t* lobe, float* htp, const int* chunks, int L,
+                    int D, int H, int W, int R, void* stream);
+
+/* 256-bin histogram of uint8(clip(htp,0,1)*255) over voxels with lobe > 0 (input of Otsu, binary_cam
+ * dram/utils.py:226-242) and the fp64 sum of htp over the same voxels.  hist: 256 x uint64, sum: 1 x double. */
+int dram_lung_hist256(const float* htp, const uint8_t* lobe, unsigned long long* hist, double* sum,
+                      int64_t n, void* stream);
+
+/* mask[v] = htp[v] > th. */
+int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

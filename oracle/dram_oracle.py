@@ -416,3 +416,77 @@ def int_reg_refine_loss(dense, lobes, lesions, ctsses, freq_map, band_width=1e-2
         pseudo = pseudo * keep
     seg = boot_bce(probs, pseudo, lobes > 0, smoothing)
     return reg, seg
+
+
+# --------------------------------------------------------------------------
+# whole-scan inference restatement (reference dram/job_runner.py:720-779, 1003-1005)
+# --------------------------------------------------------------------------
+def windowing(image, from_span, to_span=(0.0, 1.0)):
+    """dram/utils.py:189-198."""
+    image = np.clip(image, a_min=from_span[0], a_max=from_span[1])
+    return ((image - from_span[0]) / float(from_span[1] - from_span[0])) * (to_span[1] - to_span[0]) + to_span[0]
+
+
+def find_crops(mask, spacing, border):
+    """dram/utils.py:244-254 (scipy.ndimage.find_objects of the whole mask = its bounding box)."""
+    idx = np.nonzero(mask)
+    sl = tuple(slice(int(i.min()), int(i.max()) + 1) for i in idx)
+    if border > 0:
+        sl = tuple(slice(max(0, o.start - int(math.ceil(border / sp))), min(ss, o.stop + int(math.ceil(border / sp))))
+                   for o, ss, sp in zip(sl, mask.shape, spacing))
+    return sl
+
+
+def threshold_otsu_u8(img_u8):
+    """skimage.filters.threshold_otsu for a uint8 array, restated from the published algorithm:
+    histogram over the occupied integer range, maximise the between-class variance.  (skimage is
+    not installed here: parity with the library itself is unpinned.)"""
+    v = np.asarray(img_u8).ravel()
+    lo, hi = int(v.min()), int(v.max())
+    hist = np.bincount(v, minlength=256)[lo:hi + 1].astype(np.float64)
+    centers = np.arange(lo, hi + 1, dtype=np.float64)
+    w1 = np.cumsum(hist)
+    w2 = np.cumsum(hist[::-1])[::-1]
+    m1 = np.cumsum(hist * centers) / w1
+    m2 = (np.cumsum((hist * centers)[::-1]) / w2[::-1])[::-1]
+    var12 = w1[:-1] * w2[1:] * (m1[:-1] - m2[1:]) ** 2
+    return float(centers[int(np.argmax(var12))])
+
+
+def binary_cam(cam_np, scaler=1.0, from_span=(0, 1)):
+    """dram/utils.py:226-242: returns (mask, th/255)."""
+    w = windowing(cam_np, from_span=from_span, to_span=(0, 255)).astype(np.uint8)
+    u = np.unique(w)
+    if len(u) < 2:
+        return np.ones_like(w).astype(bool), u[0] / 255.0
+    th = min(threshold_otsu_u8(w) * scaler, 255.0)
+    return w >= th, th / 255.0
+
+
+def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", resample=80,
+                  window=(-1000.0, -300.0), border=5.0):
+    """evaluate_scan (job_runner.py:729-770) + the thresholding of LesionSegTest.run
+    (job_runner.py:1003-1005), one lobe at a time like the reference.  The crop -> resample^3 step
+    uses trilinear/align_corners (this build's definition, see dram_amd/inference.py)."""
+    htp = np.zeros(scan.shape, dtype=np.float32)
+    with torch.no_grad():
+        for label in np.unique(lobe)[1:]:
+            lobe_binary = lobe == label
+            sl = find_crops(lobe_binary, spacing, border)
+            lobe_chunk = lobe_binary[sl]
+            scan_chunk = scan[sl].astype(np.float32).copy()
+            crop_size = lobe_chunk.shape
+            scan_chunk[lobe_chunk == 0] = -2048
+            img = windowing(scan_chunk, from_span=window, to_span=(0.0, 1.0)).astype(np.float32)
+            t = torch.from_numpy(img)[None, None]
+            t = upsample_trilinear_ac(t, size=(resample,) * 3)
+            dense = dc3d_forward(cfg, params, buffers, t, training=False, norm_method=norm_method)
+            probs = torch.sigmoid(dense)
+            probs = upsample_trilinear_ac(probs, size=tuple(crop_size))[0, 0].numpy()
+            view = htp[sl]
+            view[lobe_chunk] = probs[lobe_chunk]
+    lung = lobe > 0
+    _, th = binary_cam(htp[lung])
+    mask = htp > th
+    ratio = float((htp * lung).sum() / lung.sum())
+    return htp, mask, th, ratio

@@ -1,0 +1,65 @@
+"""GPU parity of the per-lobe whole-scan inference path (BASELINE config 5 at
+reduced size) against the CPU oracle's restatement of evaluate_scan + binary_cam."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dram_oracle as O
+from oracle.make_golden import SLIM
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(norm="bn"):
+    import models
+    torch.manual_seed(3)
+    m = models.DC3D(**SLIM, norm_method=norm)
+    m.init(models.HeNorm(mode="fan_in"))
+    # non-trivial running statistics so that eval-mode BatchNorm is exercised
+    g = torch.Generator().manual_seed(4)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm3d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    return m
+
+
+@pytest.mark.parametrize("shape,spacing,R", [((60, 96, 96), (1.0, 0.7, 0.7), 32), ((41, 57, 66), (2.5, 1.0, 1.0), 24)])
+def test_lobe_inference_matches_oracle(shape, spacing, R):
+    from dram_amd.inference import LobeInference, dice, synthetic_ct
+    scan, lobe, spacing = synthetic_ct(shape, spacing, seed=7, n_lesions=8)
+    model = _model()
+    params, buffers = O.split_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    model = model.cuda().eval()
+    res = LobeInference(model, resample_size=R).run(scan, lobe, spacing)
+    htp_ref, mask_ref, th_ref, ratio_ref = O.evaluate_scan(SLIM, params, buffers, scan, lobe, spacing, resample=R)
+    # crops (find_crops with the 5 mm border)
+    for c in res["chunks"]:
+        sl = O.find_crops(lobe == c[6], spacing, 5.0)
+        assert [s.start for s in sl] == c[:3] and [s.stop - s.start for s in sl] == c[3:6]
+    htp = res["htp"].cpu().numpy()
+    assert np.abs(htp - htp_ref).max() <= 1e-4 * max(1.0, np.abs(htp_ref).max())
+    assert (htp[lobe == 0] == 0).all()
+    assert abs(res["threshold"] - th_ref) <= 1.0 / 255.0 + 1e-9        # the 8-bit Otsu bin may move by at most one
+    d = dice(res["mask"].cpu().numpy(), mask_ref, 1e-5)
+    assert d >= 0.999, d
+    assert abs(res["lesion_ratio"] - ratio_ref) <= 1e-5 * max(1.0, abs(ratio_ref))
+
+
+def test_inference_kernels_edge_cases():
+    """absent labels, a single-voxel-thick lobe, windowing limits."""
+    from dram_amd.inference import LobeInference
+    scan = np.full((12, 20, 24), -1000, dtype=np.int16)
+    lobe = np.zeros(scan.shape, dtype=np.uint8)
+    lobe[3:9, 4:15, 5:20] = 2          # label 1 absent
+    lobe[10, 2:6, 3:9] = 5             # one slice thick
+    scan[lobe == 2] = -300             # window maximum -> 1.0
+    scan[lobe == 5] = 500              # above the window -> clipped to 1.0
+    model = _model().cuda().eval()
+    res = LobeInference(model, resample_size=16).run(scan, lobe, (1.0, 1.0, 1.0))
+    assert [c[6] for c in res["chunks"]] == [2, 5]
+    x = res["input"].cpu().numpy()
+    assert x.min() >= 0.0 and abs(x.max() - 1.0) < 1e-6
+    params, buffers = O.split_state_dict({k: v.cpu().clone() for k, v in model.state_dict().items()})
+    htp_ref, mask_ref, th_ref, _ = O.evaluate_scan(SLIM, params, buffers, scan, lobe, (1.0, 1.0, 1.0), resample=16)
+    assert np.abs(res["htp"].cpu().numpy() - htp_ref).max() <= 1e-4
