@@ -494,6 +494,98 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward-weights of the FIRST layer (Cin == 1, e.g. DC3D ds_modules.0 conv 1->32).  The generic
+// kernel would run its 16/32-wide input-channel tile 1/32 full; here the 27 taps of the single input
+// channel play the role of the GEMM's N dimension instead:
+//     dW[co][tap] = sum_v dY[co][v] * X[v + tap]        M = co (32), N = tap (27 of 32), K = voxels
+// on v_mfma_f32_32x32x2_f32 (A[co][k] = dY[co][v+k], B[k][tap] = X[v+k+off(tap)], both from LDS).
+// HBM-bound (reads dY once: 4*Cout B/voxel).  Block = 256 voxels (32x4x2 box) x 32 co, 4 waves x 64
+// voxels; per-wave partial slabs, reduced in a fixed order by slab_reduce_kernel.
+struct WgradC1Args {
+    const float* x;   // [N][1][D][H][W]
+    const float* dy;  // [N][Cout][D][H][W]
+    float* slabs;     // [4*gridDim.x][Cout][27]
+    int N, Cout, D, H, W;
+    int nbx, nby, nbz, nboxes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_c1_kernel(WgradC1Args a) {
+    constexpr int BX = 32, BY = 4, BZ = 2, VOX = 256;
+    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HV = HX * HY * HZ;   // 816
+    constexpr int PA = VOX + 1;   // odd co stride: conflict-free A reads
+    constexpr int NQ = (HV + 255) / 256;
+    __shared__ float ldy[32 * PA];
+    __shared__ float lx[HV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.y * 32;
+    const int D = a.D, H = a.H, W = a.W;
+    const int S = D * H * W;
+    const unsigned S4 = 4u * (unsigned)S;
+    const int i = lane & 31, k = lane >> 5;     // A: co = i, voxel k ; B: tap = i, voxel k
+    const int tap = i < 27 ? i : 0;
+    const int tapoff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+    const bool tap_ok = i < 27;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int box = blockIdx.x; box < a.nboxes; box += gridDim.x) {
+        int bb = box;
+        const int bx = bb % a.nbx; bb /= a.nbx;
+        const int by = bb % a.nby; bb /= a.nby;
+        const int bz = bb % a.nbz;
+        const int n = bb / a.nbz;
+        const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+        __syncthreads();
+        {   // dY[32][256]: thread = voxel, 32 channel rows (rows beyond Cout are out of the descriptor's range -> 0)
+            const int vx = tid % BX, vy = (tid / BX) % BY, vz = tid / (BX * BY);
+            const bool vok = (x0 + vx) < W && (y0 + vy) < H && (z0 + vz) < D;
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), (unsigned)a.Cout * S4);
+            unsigned run = vok ? 4u * (unsigned)(((z0 + vz) * H + y0 + vy) * W + x0 + vx) + (unsigned)co0 * S4 : OOB;
+            const unsigned inc = vok ? S4 : 0u;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                ldy[c * PA + tid] = buf_load(srd, run, 0);
+                run += inc;
+            }
+            const __amdgpu_buffer_rsrc_t srx = make_rsrc(uniform_ptr(a.x + (size_t)n * S), S4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int e = tid + 256 * q;
+                const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
+                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                const bool ok = e < HV && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+                const float v = buf_load(srx, ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB, 0);
+                if (e < HV) lx[e] = v;
+            }
+        }
+        __syncthreads();
+        // wave w: voxels [64w, 64w+64) = 2 x-rows; 32 k-steps of 2 voxels
+        const float* ap = ldy + i * PA + 64 * wave + k;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int v = 64 * wave + 2 * s + k;            // this lane's voxel of the k-step
+            const int vx = v % BX, vy = (v / BX) % BY, vz = v / (BX * BY);
+            const float av = ap[2 * s];
+            float bv = lx[(vz * HY + vy) * HX + vx + tapoff];
+            bv = tap_ok ? bv : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    // D[row = co][col = tap]: lane col = lane&31, rows (r&3)+8(r>>2)+4k
+    if (tap_ok) {
+        float* slab = a.slabs + ((size_t)(blockIdx.x * 4 + wave) * a.Cout) * 27;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * k;
+            if (co < a.Cout) slab[(size_t)co * 27 + i] = acc[r];
+        }
+    }
+}
+
+static inline int wgrad_c1_blocks(int nboxes) { return nboxes < 1024 ? nboxes : 1024; }
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t E, int split) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -692,6 +784,10 @@ extern "C" int dram_conv3d_k3_fwd_cat(const float* x1, int C1, const float* x2, 
 
 extern "C" size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D, int H, int W) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (Cin == 1) {
+        const int64_t nboxes = (int64_t)N * cdiv(W, 32) * cdiv(H, 4) * cdiv(D, 2);
+        return (size_t)4 * wgrad_c1_blocks((int)(nboxes < 0x7fffffff ? nboxes : 0x7fffffff)) * Cout * 27 * sizeof(float);
+    }
     const WgradPlan p = wgrad_plan(N, Cin, Cout, D, H, W);
     return (size_t)p.split * Cout * Cin * 27 * sizeof(float);
 }
@@ -712,6 +808,31 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     int rc = check_conv_shape("conv3d_k3_wgrad", N, a.Cin, Cout, D, H, W);
     if (rc) return rc;
     if ((rc = check_cat("conv3d_k3_wgrad(src)", a.src, D, H, W))) return rc;
+    if (a.Cin == 1 && x2 == nullptr) {   // first layer: dedicated kernel
+        DRAM_REQUIRE(((int64_t)Cout + 32) * (int64_t)D * H * W < 0x3fffffffLL,
+                     "conv3d_k3_wgrad: (channels + 32) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
+        WgradC1Args c;
+        c.x = x1; c.dy = dy; c.slabs = (float*)ws;
+        c.N = N; c.Cout = Cout; c.D = D; c.H = H; c.W = W;
+        c.nbx = cdiv(W, 32); c.nby = cdiv(H, 4); c.nbz = cdiv(D, 2);
+        const int64_t nb = (int64_t)N * c.nbx * c.nby * c.nbz;
+        DRAM_REQUIRE(nb < 0x7fffffffLL, "conv3d_k3_wgrad: too many boxes");
+        c.nboxes = (int)nb;
+        const int blocks = wgrad_c1_blocks(c.nboxes);
+        const size_t need1 = (size_t)4 * blocks * Cout * 27 * sizeof(float);
+        if (ws_bytes < need1) {
+            set_error("conv3d_k3_wgrad: workspace %zu < %zu bytes", ws_bytes, need1);
+            return DRAM_EWS;
+        }
+        hipStream_t st1 = (hipStream_t)stream;
+        hipLaunchKernelGGL(conv3d_k3_wgrad_c1_kernel, dim3(blocks, cdiv(Cout, 32)), dim3(256), 0, st1, c);
+        const int64_t E1 = (int64_t)Cout * 27;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E1, 256)), dim3(256), 0, st1, c.slabs, dw, E1, 4 * blocks);
+        return check_launch("conv3d_k3_wgrad(c1)");
+    }
+    // running 32-bit offsets walk up to 128 channel planes past the last one: they must not wrap
+    DRAM_REQUIRE(((int64_t)(a.Cin > Cout ? a.Cin : Cout) + 128) * (int64_t)D * H * W < 0x3fffffffLL,
+                 "conv3d_k3_wgrad: (channels + 128) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
     const WgradPlan p = wgrad_plan(N, a.Cin, Cout, D, H, W);
     const size_t need = (size_t)p.split * Cout * a.Cin * 27 * sizeof(float);
     if (ws_bytes < need) {

@@ -61,7 +61,9 @@ def conv_fwd_kernel_name(W, Cout):
     return f"conv3d_k3_fwd_kernel<{box}, {1 if Cout <= 32 else 2}>"
 
 
-def conv_wgrad_kernel_name(W, Cout):
+def conv_wgrad_kernel_name(W, Cout, Cin=None):
+    if Cin == 1:
+        return "conv3d_k3_wgrad_c1_kernel"
     box = "32, 2, 1" if W >= 24 else ("16, 2, 2" if W >= 12 else "8, 4, 2")
     return f"conv3d_k3_wgrad_kernel<{box}, {'8, 1' if Cout > 64 else '4, 2'}>"
 
@@ -168,7 +170,7 @@ class Conv3dK3Fn(Function):
             nbytes = _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)
             ws = _ws(nbytes, dy.device)
             vox = N * D * H * W
-            _timed_call(conv_wgrad_kernel_name(W, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_wgrad_kernel_name(W, Co, Ci if x2 is None else None), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
                         _p(ws), ws.numel(), N, Co, D, H, W, st)
         if ctx.has_bias and ctx.needs_input_grad[3]:

@@ -50,6 +50,8 @@ CONV_CASES = [
     (2, 20, 70, 8, 8, 16, False),     # Cout not a multiple of 64, Cin not a multiple of 4/16
     (1, 64, 64, 4, 36, 36, False),
     (1, 130, 40, 3, 5, 20, True),     # Cin > 128
+    (2, 1, 40, 5, 9, 35, False),      # Cin = 1 with two 32-channel output tiles (first-layer wgrad kernel)
+    (3, 1, 8, 4, 4, 6, True),         # Cin = 1, tiny
 ]
 
 
