@@ -61,8 +61,8 @@ struct FwdGeom {
     static constexpr int COB = 32 * COT;
     static constexpr int NQ = (HV + 255) / 256;
     static constexpr int WROWS = 27 * KC;
-    static constexpr int RPT = 256 / COB;  // weight rows staged per pass
-    static constexpr int WPASS = (WROWS + RPT - 1) / RPT;
+    static constexpr int WSLOTS = WROWS * COB / 4;             // 16-byte slots of the weight tile
+    static constexpr int WPASS = (WSLOTS + 255) / 256;          // dwordx4 loads per thread and chunk
     static constexpr int STAGE = KC * PS + WROWS * COB;  // floats per LDS stage
     static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
 };
@@ -77,6 +77,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
 }
 __device__ __forceinline__ const float* uniform_ptr(const float* p) {
     const unsigned long long v = (unsigned long long)p;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     static_assert(BX * BY * BZ == 256, "block covers 256 voxels");
     using G = FwdGeom<BX, BY, BZ, COT>;
     constexpr int HX = G::HX, HY = G::HY, HV = G::HV, PS = G::PS, COB = G::COB, NQ = G::NQ;
-    constexpr int WROWS = G::WROWS, RPT = G::RPT, WPASS = G::WPASS, STAGE = G::STAGE;
+    constexpr int WSLOTS = G::WSLOTS, WPASS = G::WPASS, STAGE = G::STAGE;
     static_assert(NQ <= 4, "halo elements per thread");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,14 +162,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     }
     const int abase = kh * COB + j;
 
-    // weights: thread (wrow, wcol) stages rows p*RPT + wrow, p = 0..WPASS-1 of the [27*KC][COB] tile
-    const int wrow = tid / COB, wcol = tid % COB;
-    const bool wcol_ok = (co0 + wcol) < a.Cout;
+    // weights: the [27*KC rows][COB] tile of a chunk is staged with 16-byte loads (a row = COB contiguous
+    // floats of wt[tap][ci][co0..]): slot f = p*256 + tid -> row f/(COB/4), columns 4*(f%(COB/4))..+3.
+    // Columns of channels >= Cout hold whatever follows in memory (finite weights, or 0 beyond the
+    // buffer): they only feed accumulator rows that the epilogue never stores.
     const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 27u * (unsigned)a.Cin * (unsigned)a.Cout * 4u);
     const unsigned tap_stride = 4u * (unsigned)a.Cin * (unsigned)a.Cout;
+    unsigned wvoff[WPASS];     // byte offset of this thread's slot p for chunk 0 (OOB for slots past the tile)
+    int wkc[WPASS];
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) {
+        const int f = p * 256 + tid;
+        const int row = f / (COB / 4), c4 = f % (COB / 4);
+        const int tap = row / KC;
+        wkc[p] = row % KC;
+        wvoff[p] = f < WSLOTS ? (unsigned)tap * tap_stride + 4u * (unsigned)(wkc[p] * a.Cout + co0 + 4 * c4) : OOB;
+    }
 
     float rin[KC][NQ];   // prefetched input halo elements of the next chunk
-    float rw[WPASS];     // prefetched weights of the next chunk
+    f32x4 rw[WPASS];     // prefetched weights of the next chunk
 
     auto load_chunk = [&](int c0) {
 #pragma unroll
@@ -178,18 +194,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rin[kc][q] = buf_load(srd, off[q], 0);
         }
+        const unsigned cbase = 4u * (unsigned)c0 * (unsigned)a.Cout;
+        if (c0 + KC <= a.Cin) {
 #pragma unroll
-        for (int p = 0; p < WPASS; ++p) {
-            const int row = p * RPT + wrow;
-            const int tap = row / KC, kc = row % KC;
-            const int ci = c0 + kc;
-            const bool ok = (RPT * WPASS == WROWS || row < WROWS) && ci < a.Cin && wcol_ok;
-            const unsigned voff = ok ? 4u * (unsigned)(ci * a.Cout + co0 + wcol) : OOB;
-            if (RPT == KC) {   // COB == 64: tap == p is uniform -> scalar offset
-                rw[p] = buf_load(wsrd, voff, (unsigned)p * tap_stride);
-            } else {
-                rw[p] = buf_load(wsrd, ok ? voff + (unsigned)tap * tap_stride : OOB, 0);
-            }
+            for (int p = 0; p < WPASS; ++p) rw[p] = buf_load4(wsrd, wvoff[p] + cbase, 0);
+        } else {   // last, partial chunk: rows of channels >= Cin must read as 0
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) rw[p] = buf_load4(wsrd, (c0 + wkc[p]) < a.Cin ? wvoff[p] + cbase : OOB, 0);
         }
     };
     auto store_chunk = [&](float* stage) {
@@ -202,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
                 if (tid + 256 * q < HV) lin[kc * PS + tid + 256 * q] = rin[kc][q];
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) {
-            const int row = p * RPT + wrow;
-            if (RPT * WPASS == WROWS || row < WROWS) lw[row * COB + wcol] = rw[p];
+            const int f = p * 256 + tid;
+            if (WPASS * 256 == WSLOTS || f < WSLOTS) *reinterpret_cast<f32x4*>(lw + 4 * f) = rw[p];
         }
     };
     auto compute = [&](const float* stage) {
