@@ -506,6 +506,213 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward-weights, 16-byte staging variant (W a multiple of the box width, channel tile inside one
+// source tensor).  Same tiling and MFMA loop as conv3d_k3_wgrad_kernel; only the way a box gets into
+// LDS differs: s_memtime stamps showed 3-5k of the 34k cycles per box going into the issue of the 40
+// dword loads per thread (320 wave-level VMEM instructions per CU and box through the vector-memory
+// path) plus 1.4k into the 40 ds_write_b32.  Here a thread moves 16-byte pieces: dY rows as float4
+// (buffer_load_dwordx4 + ds_write_b128), X halo rows as 8 aligned float4 of interior + 2 edge dwords
+// (rows padded to BX+8 floats so that the interior starts 16-byte aligned) -> 10-12 VMEM instructions.
+template <int BX, int BY, int BZ, int COS, int CIT>
+struct WgradVecGeom {
+    static constexpr int T = 512;
+    static constexpr int VOX = BX * BY * BZ;
+    static constexpr int PA = VOX + 4;                  // multiple of 4: ds_write_b128 rows (A reads 2-way conflicted: 1 of 28 reads)
+    static constexpr int HY = BY + 2, HZ = BZ + 2;
+    static constexpr int HXP = BX + 8;                  // padded halo row: [3 pad][left][BX interior][right][3 pad]
+    static constexpr int RPC = HY * HZ;                 // halo rows per channel
+    static constexpr int PB = PadTo2Mod32<RPC * HXP>::value;
+    static constexpr int CO_B = 16 * COS, CI_B = 16 * CIT;
+    // a thread keeps the same (row, column) role in every pass and only the channel advances, by a fixed
+    // number of channels per pass: one base offset and one validity test per kind of slot instead of one
+    // per slot (registers are what this kernel is short of)
+    static constexpr int DY_TPC = VOX / 4, DY_CPP = T / DY_TPC, DYP = (CO_B + DY_CPP - 1) / DY_CPP;       // dY float4 slots
+    static constexpr int XI_TPC = RPC * (BX / 4), XI_CPP = T / XI_TPC, XIP = (CI_B + XI_CPP - 1) / XI_CPP; // X interior float4 slots
+    static constexpr int XE_TPC = RPC * 2, XE_CPP = T / XE_TPC, XEP = (CI_B + XE_CPP - 1) / XE_CPP;       // X edge dword slots
+    static constexpr size_t LDS_BYTES = (size_t)(CO_B * PA + CI_B * PB) * sizeof(float);
+};
+
+template <int BX, int BY, int BZ, int COS, int CIT>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a) {
+    using G = WgradVecGeom<BX, BY, BZ, COS, CIT>;
+    constexpr int VOX = G::VOX, PA = G::PA, HY = G::HY, HXP = G::HXP, PB = G::PB;
+    constexpr int CO_B = G::CO_B, CI_B = G::CI_B, DYP = G::DYP, XIP = G::XIP, XEP = G::XEP;
+    constexpr int DY_TPC = G::DY_TPC, DY_CPP = G::DY_CPP, XI_TPC = G::XI_TPC, XI_CPP = G::XI_CPP, XE_TPC = G::XE_TPC, XE_CPP = G::XE_CPP;
+    static_assert(COS * CIT == 8 && BX % 4 == 0 && PB % 2 == 0 && VOX % 4 == 0 && DY_CPP >= 1 && XI_CPP >= 1 && XE_CPP >= 1,
+                  "block geometry");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldy = lds;             // [CO_B][PA]
+    float* lx = lds + CO_B * PA;  // [CI_B][PB], row r of channel c at c*PB + r*HXP, halo x index h at column h+3
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % COS, wci = wave / COS;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = b % a.ci_tiles; b /= a.ci_tiles;
+    const int co_t = b % a.co_tiles;
+    const int sp = b / a.co_tiles;
+    const int ci0 = ci_t * CI_B, co0 = co_t * CO_B;
+    const int D = a.D, H = a.H, W = a.W;
+    const int S = D * H * W;
+    // the source tensor of this block's channel tile (the host guarantees the tile does not straddle)
+    const bool use2 = a.src.p2 != nullptr && ci0 >= a.src.C1;
+    const int Hs = use2 ? a.src.H2 : H, Ws = use2 ? a.src.W2 : W;
+    const int Ss = use2 ? a.src.D2 * a.src.H2 * a.src.W2 : S;
+    const int oz = use2 ? a.src.oz : 0, oy = use2 ? a.src.oy : 0, ox = use2 ? a.src.ox : 0;
+    const int Cs = use2 ? a.src.C2 : a.src.C1;
+    const int cs0 = use2 ? ci0 - a.src.C1 : ci0;          // first channel of the tile inside its tensor
+    const float* xs = use2 ? a.src.p2 : a.src.p1;
+    const unsigned S4 = 4u * (unsigned)S, Ss4 = 4u * (unsigned)Ss;
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int i = lane & 15, k = lane >> 4;
+
+    f32x4 rdy[DYP];
+    f32x4 rxi[XIP];
+    float rxe[XEP];
+
+    // thread-constant slot roles
+    // dY: channel d_c + p*DY_CPP, 4 voxels starting at (d_vz, d_vy, d_vx)
+    const int d_c = tid / DY_TPC, d_v = 4 * (tid % DY_TPC);
+    const int d_vx = d_v % BX, d_vy = (d_v / BX) % BY, d_vz = d_v / (BX * BY);
+    const bool d_act = d_c < DY_CPP;
+    const unsigned d_rel = (unsigned)(co0 + d_c) * S4 + 4u * (unsigned)((d_vz * H + d_vy) * W + d_vx);
+    // X interior: channel i_c + p*XI_CPP, halo row (i_hz, i_hy), columns 4*i_j..+3
+    const int i_c = tid / XI_TPC, i_r = (tid % XI_TPC) / (BX / 4), i_j = tid % (BX / 4);
+    const int i_hy = i_r % HY, i_hz = i_r / HY;
+    const bool i_act = i_c < XI_CPP;
+    const unsigned i_rel = (unsigned)(cs0 + i_c) * Ss4 + 4u * (unsigned)((i_hz * Hs + i_hy) * Ws + 4 * i_j);
+    // X edges: channel e_c + p*XE_CPP, halo row (e_hz, e_hy), side 0 = x0-1, 1 = x0+BX
+    const int e_c = tid / XE_TPC, e_r = (tid % XE_TPC) / 2, e_side = tid % 2;
+    const int e_hy = e_r % HY, e_hz = e_r / HY;
+    const bool e_act = e_c < XE_CPP;
+    const unsigned e_rel = (unsigned)(cs0 + e_c) * Ss4 + 4u * (unsigned)((e_hz * Hs + e_hy) * Ws + (e_side ? BX : -1));
+
+    auto load_box = [&](int box) {
+        int bb = box;
+        const int bx = bb % a.nbx; bb /= a.nbx;
+        const int by = bb % a.nby; bb /= a.nby;
+        const int bz = bb % a.nbz;
+        const int n = bb / a.nbz;
+        const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+        {   // dY: rows of the box are full in x (W % BX == 0); rows beyond H / D read 0, and so do channels
+            // >= Cout (their offset is beyond the descriptor's num_records)
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), (unsigned)a.Cout * S4);
+            const bool ok = d_act && (y0 + d_vy) < H && (z0 + d_vz) < D;
+            unsigned run = ok ? 4u * (unsigned)((z0 * H + y0) * W + x0) + d_rel : OOB;
+            const unsigned inc = ok ? (unsigned)DY_CPP * S4 : 0u;
+#pragma unroll
+            for (int p = 0; p < DYP; ++p) {
+                rdy[p] = buf_load4(srd, (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B) ? run : OOB, 0);
+                run += inc;
+            }
+        }
+        {   // X halo rows: halo origin = (z0-1, y0-1, x0) of the (cropped) source plane
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(xs + (size_t)n * Cs * Ss), (unsigned)Cs * Ss4);
+            const unsigned origin = 4u * (unsigned)(((z0 - 1 + oz) * Hs + (y0 - 1 + oy)) * Ws + x0 + ox);   // may wrap for rows above the volume: those are invalid
+            {
+                const bool ok = i_act && (unsigned)(y0 - 1 + i_hy) < (unsigned)H && (unsigned)(z0 - 1 + i_hz) < (unsigned)D;
+                unsigned run = ok ? origin + i_rel : OOB;
+                const unsigned inc = ok ? (unsigned)XI_CPP * Ss4 : 0u;
+#pragma unroll
+                for (int p = 0; p < XIP; ++p) {
+                    rxi[p] = buf_load4(srd, (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B) ? run : OOB, 0);
+                    run += inc;
+                }
+            }
+            {
+                const bool ok = e_act && (unsigned)(y0 - 1 + e_hy) < (unsigned)H && (unsigned)(z0 - 1 + e_hz) < (unsigned)D &&
+                                (e_side ? (x0 + BX) < W : x0 > 0);
+                unsigned run = ok ? origin + e_rel : OOB;
+                const unsigned inc = ok ? (unsigned)XE_CPP * Ss4 : 0u;
+#pragma unroll
+                for (int p = 0; p < XEP; ++p) {
+                    rxe[p] = buf_load(srd, (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B) ? run : OOB, 0);
+                    run += inc;
+                }
+            }
+        }
+    };
+    auto store_box = [&]() {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int p = 0; p < DYP; ++p)
+            if (d_act && (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B))
+                *reinterpret_cast<f32x4*>(ldy + (d_c + p * DY_CPP) * PA + d_v) = rdy[p];
+#pragma unroll
+        for (int p = 0; p < XIP; ++p)
+            if (i_act && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B)) {
+                float* d = lx + (i_c + p * XI_CPP) * PB + i_r * HXP + 4 + 4 * i_j;       // 8-byte aligned
+                *reinterpret_cast<f32x2*>(d) = f32x2{rxi[p][0], rxi[p][1]};
+                *reinterpret_cast<f32x2*>(d + 2) = f32x2{rxi[p][2], rxi[p][3]};
+            }
+#pragma unroll
+        for (int p = 0; p < XEP; ++p)
+            if (e_act && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B))
+                lx[(e_c + p * XE_CPP) * PB + e_r * HXP + (e_side ? BX + 4 : 3)] = rxe[p];
+    };
+    auto compute = [&]() {
+        const float* ap = ldy + (wco * 16 + i) * PA + k;
+        const float* bp = lx + (wci * 16 + i) * PB + k + 3;
+        constexpr int NS = VOX / 4;
+        float av[2], bv[2][27];
+#pragma unroll
+        for (int s = 0; s <= NS; ++s) {
+            if (s < NS) {
+                const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
+                av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
+                const float* bq = bp + (vz * HY + vy) * HXP + 4 * x4;
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) {
+                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                    bv[s & 1][tap] = bq[(dz * HY + dy) * HXP + dx];
+                }
+            }
+            if (s > 0) {
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(s - 1) & 1], bv[(s - 1) & 1][tap], acc[tap], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (sp < a.nboxes) {
+        load_box(sp);
+        store_box();
+    }
+    __syncthreads();
+    for (int box = sp; box < a.nboxes; box += a.split) {
+        const bool has_next = (box + a.split) < a.nboxes;
+        if (has_next) load_box(box + a.split);
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+            __syncthreads();
+            store_box();
+            __syncthreads();
+        }
+    }
+
+    const int ci = ci0 + wci * 16 + i;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wco * 16 + 4 * k + r;
+            if (co < a.Cout) {
+                float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) o[tap] = acc[tap][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weights of the FIRST layer (Cin == 1, e.g. DC3D ds_modules.0 conv 1->32).  The generic
 // kernel would run its 16/32-wide input-channel tile 1/32 full; here the 27 taps of the single input
 // channel play the role of the GEMM's N dimension instead:
@@ -706,6 +913,24 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W) {
 }
 
 template <int BX, int BY, int BZ, int COS, int CIT>
+static int launch_wgrad_vec(WgradArgs& a, hipStream_t st) {
+    using G = WgradVecGeom<BX, BY, BZ, COS, CIT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DRAM_EHIP;
+        }
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
+    return check_launch("conv3d_k3_wgrad(vec)");
+}
+
+template <int BX, int BY, int BZ, int COS, int CIT>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
     using G = WgradGeom<BX, BY, BZ, COS, CIT>;
     static bool attr_done = false;
@@ -853,7 +1078,20 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     a.nbx = p.nbx; a.nby = p.nby; a.nbz = p.nbz; a.nboxes = p.nboxes;
     a.split = p.split; a.ci_tiles = p.ci_tiles; a.co_tiles = p.co_tiles;
     hipStream_t st = (hipStream_t)stream;
-    if (p.variant == 1) {
+    // 16-byte staging needs full boxes along x and a channel tile that lies inside one source tensor
+    const int ci_b = p.variant == 1 ? 16 : 32;
+    const bool vec = (W % p.bx == 0) && (x2 == nullptr || C1 % ci_b == 0) && getenv("DRAM_WGRAD_NOVEC") == nullptr;
+    if (vec) {
+        if (p.variant == 1) {
+            if (p.bx == 32) rc = launch_wgrad_vec<32, 2, 1, 8, 1>(a, st);
+            else if (p.bx == 16) rc = launch_wgrad_vec<16, 2, 2, 8, 1>(a, st);
+            else rc = launch_wgrad_vec<8, 4, 2, 8, 1>(a, st);
+        } else {
+            if (p.bx == 32) rc = launch_wgrad_vec<32, 2, 1, 4, 2>(a, st);
+            else if (p.bx == 16) rc = launch_wgrad_vec<16, 2, 2, 4, 2>(a, st);
+            else rc = launch_wgrad_vec<8, 4, 2, 4, 2>(a, st);
+        }
+    } else if (p.variant == 1) {
         if (p.bx == 32) rc = launch_wgrad<32, 2, 1, 8, 1>(a, st);
         else if (p.bx == 16) rc = launch_wgrad<16, 2, 2, 8, 1>(a, st);
         else rc = launch_wgrad<8, 4, 2, 8, 1>(a, st);

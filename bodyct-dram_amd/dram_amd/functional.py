@@ -64,8 +64,10 @@ def conv_fwd_kernel_name(W, Cout):
 def conv_wgrad_kernel_name(W, Cout, Cin=None):
     if Cin == 1:
         return "conv3d_k3_wgrad_c1_kernel"
-    box = "32, 2, 1" if W >= 24 else ("16, 2, 2" if W >= 12 else "8, 4, 2")
-    return f"conv3d_k3_wgrad_kernel<{box}, {'8, 1' if Cout > 64 else '4, 2'}>"
+    bx = 32 if W >= 24 else (16 if W >= 12 else 8)
+    box = {32: "32, 2, 1", 16: "16, 2, 2", 8: "8, 4, 2"}[bx]
+    kind = "wgrad_vec" if W % bx == 0 else "wgrad"       # 16-byte staging needs full boxes along x
+    return f"conv3d_k3_{kind}_kernel<{box}, {'8, 1' if Cout > 64 else '4, 2'}>"
 
 
 def _p(t):

@@ -52,6 +52,9 @@ CONV_CASES = [
     (1, 130, 40, 3, 5, 20, True),     # Cin > 128
     (2, 1, 40, 5, 9, 35, False),      # Cin = 1 with two 32-channel output tiles (first-layer wgrad kernel)
     (3, 1, 8, 4, 4, 6, True),         # Cin = 1, tiny
+    (1, 40, 72, 3, 5, 32, False),     # W a multiple of the box width: 16-byte staging path of wgrad (32-wide)
+    (2, 24, 130, 4, 6, 16, False),    # ... 16-wide boxes, Cout > 128
+    (1, 16, 16, 9, 6, 8, True),       # ... 8-wide boxes
 ]
 
 
@@ -80,14 +83,16 @@ def test_conv3d_k3_fwd_bwd(case):
 
 @pytest.mark.parametrize("shape", [((2, 6, 4, 6, 8), (2, 5, 4, 6, 8)),       # same size: identity crop
                                    ((2, 6, 6, 10, 12), (2, 4, 7, 11, 13)),   # crop offsets (1,1,1) (ceil)
-                                   ((1, 3, 5, 6, 20), (1, 9, 8, 9, 24))])
+                                   ((1, 3, 5, 6, 20), (1, 9, 8, 9, 24)),
+                                   ((1, 32, 4, 4, 16), (1, 16, 6, 7, 19)),    # vector wgrad path, crop offset (1,2,2), tile-aligned C1
+                                   ((2, 16, 3, 4, 32), (2, 5, 3, 4, 32))])    # vector wgrad path for Cout > 64 tiles (16-channel tiles)
 def test_conv3d_k3_virtual_concat(shape):
     """conv(crop_concat_5d(up, skip)) without materialising the concatenation."""
     from dram_amd import functional as HF
     s1, s2 = shape
     up = torch.randn(*s1, generator=g(5))
     skip = torch.randn(*s2, generator=g(6))
-    Ci, Co = s1[1] + s2[1], 10
+    Ci, Co = s1[1] + s2[1], (72 if s1[-1] == 32 else 10)   # 72 output channels -> 128x16 tiles
     w = torch.randn(Co, Ci, 3, 3, 3, generator=g(7)) / (Ci * 27) ** 0.5
     gy = torch.randn(s1[0], Co, *s1[2:], generator=g(8))
     ur, sr, wr = up.clone().requires_grad_(True), skip.clone().requires_grad_(True), w.clone().requires_grad_(True)
