@@ -48,6 +48,10 @@ SIGNATURES = {
     "dram_lobe_paste": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dram_lung_hist256": (I, [P, P, P, P, L, P]),
     "dram_threshold_mask": (I, [P, P, F, L, P]),
+    "dram_intreg_loss_ws_bytes": (Z, [I, L]),
+    "dram_intreg_loss_state_floats": (I, [I]),
+    "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),
+    "dram_intreg_loss_bwd": (I, [P, P, P, P, P, P, P, P, F, P, I, L, P]),
 }
 
 

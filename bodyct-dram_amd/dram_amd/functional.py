@@ -439,3 +439,48 @@ class MaskedMeanFn(Function):
 
 def masked_mean(x, mask):
     return MaskedMeanFn.apply(x, mask)
+
+
+# --------------------------------------------------------------------------- fused IntRegRefineLoss
+class IntRegRefineLossFn(Function):
+    """(reg_loss, seg_loss) of IntRegRefineLoss.__call__ (reference dram/metrics.py:360-373) for a model
+    whose two outputs are the same tensor (DC3D): one streaming pass for every sum, one for the gradient."""
+
+    @staticmethod
+    def forward(ctx, dense, lobes, lesions, keep, targets, weight, smoothing):
+        dense = _chk(dense, "loss dense", 5)
+        lobes = _chk(lobes, "loss lobes", 5)
+        lesions = _chk(lesions, "loss lesions", 5)
+        N = dense.shape[0]
+        S = dense.numel() // N
+        if dense.shape[1] != 1 or lobes.shape != dense.shape or lesions.shape != dense.shape:
+            raise ValueError("IntRegRefineLossFn: dense / lobes / lesions must all be [N,1,D,H,W]")
+        keep, targets, weight = _chk(keep, "loss keep").reshape(-1), _chk(targets, "loss targets"), _chk(weight, "loss weight")
+        if keep.numel() != N or targets.numel() != 2 * N or weight.numel() != N:
+            raise ValueError("IntRegRefineLossFn: keep[N], targets[N,2], weight[N] expected")
+        dev = dense.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        state = torch.empty(_lib.lib.dram_intreg_loss_state_floats(N), dtype=torch.float32, device=dev)
+        ws = _ws(_lib.lib.dram_intreg_loss_ws_bytes(N, S), dev)
+        call("dram_intreg_loss_fwd", _p(dense), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight),
+             float(smoothing), _p(out), _p(state), _p(ws), ws.numel(), N, S, _stream())
+        ctx.save_for_backward(dense, lobes, lesions, keep, targets, weight, state)
+        ctx.smoothing = float(smoothing)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        dense, lobes, lesions, keep, targets, weight, state = ctx.saved_tensors
+        gout = _chk(gout, "loss grad_output", 1)
+        N = dense.shape[0]
+        S = dense.numel() // N
+        ddense = torch.empty_like(dense)
+        call("dram_intreg_loss_bwd", _p(dense), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight), _p(state),
+             _p(gout), ctx.smoothing, _p(ddense), N, S, _stream())
+        return ddense, None, None, None, None, None, None
+
+
+def intreg_refine_loss(dense, lobes, lesions, keep, targets, weight, smoothing=0.1):
+    """Returns a [2] tensor: (reg_loss, seg_loss)."""
+    return IntRegRefineLossFn.apply(dense, lobes, lesions, keep, targets, weight, smoothing)

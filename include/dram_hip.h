@@ -198,6 +198,22 @@ int dram_lung_hist256(const float* htp, const uint8_t* lobe, unsigned long long*
 /* mask[v] = htp[v] > th. */
 int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, void* stream);
 
+/* ---- IntRegRefineLoss, fused and device resident: dram/metrics.py:158-177 (interval hinge on
+ *      the lobe-mean probability), 331-358 + 17-51 (pseudo label + BootBinCrossEntropy), 360-373 ----
+ * dense, lobes, lesions: [N,1,D,H,W] (S = D*H*W); keep[N] = 0 where the CT severity score is 0 (pseudo label
+ * forced to background, metrics.py:326-327), 1 otherwise; targets[N][2] = regression band (get_labels,
+ * metrics.py:122-138); weight[N] = clamp(frequency, 0.2, 0.8) (metrics.py:172-174).
+ * out[2] = {reg_loss, seg_loss}; state (dram_intreg_loss_state_floats(N) floats) feeds the backward. */
+size_t dram_intreg_loss_ws_bytes(int N, int64_t S);
+int dram_intreg_loss_state_floats(int N);
+int dram_intreg_loss_fwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
+                         const float* targets, const float* weight, float smoothing, float* out, float* state,
+                         void* ws, size_t ws_bytes, int N, int64_t S, void* stream);
+/* ddense = d(gout[0]*reg + gout[1]*seg)/d dense; gout is a DEVICE array of 2 floats. */
+int dram_intreg_loss_bwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
+                         const float* targets, const float* weight, const float* state, const float* gout,
+                         float smoothing, float* ddense, int N, int64_t S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""GPU parity of the training step around DC3D: the fused IntRegRefineLoss kernels
+(csrc/loss.hip, through the C ABI) against the reference's golden loss vector and against the CPU
+oracle's restatement in fp64, and one full DataParallelTrainer step of the slim DC3D against the
+oracle's forward + autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dram_oracle as O
+from oracle.make_golden import SLIM
+
+pytestmark = pytest.mark.gpu
+FREQ = {k: 1.0 / 6 for k in range(6)}
+
+
+def _batch(z, dev):
+    from dram_amd.train_step import Batch
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    return Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), FREQ, band_width=1e-2)
+
+
+def test_fused_loss_matches_reference_golden(golden_dir):
+    """tests/golden/loss.npz was produced by the reference's IntRegRefineLoss (oracle/make_golden.py)."""
+    from dram_amd.train_step import DeviceIntRegRefineLoss
+    z = np.load(os.path.join(golden_dir, "loss.npz"))
+    batch = _batch(z, "cuda")
+    dense = torch.from_numpy(z["dense"]).cuda().requires_grad_(True)
+    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dense, batch)
+    assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
+    assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
+    (2.0 * reg + 1.0 * seg).backward()
+    ref = z["gdense"]
+    assert np.abs(dense.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()   # fp32 tolerance
+
+
+@pytest.mark.parametrize("n,shape,scale", [(3, (9, 17, 23), 3.0), (5, (32, 32, 32), 1.0), (2, (1, 1, 7), 30.0)])
+def test_fused_loss_matches_oracle_fp64(n, shape, scale):
+    """Ragged sizes (not a multiple of the chunk), saturated logits (the eps clamp and its zero
+    gradient), a ctss==0 sample (pseudo label forced to background) -- against the oracle in fp64."""
+    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    g = torch.Generator().manual_seed(11)
+    dense = torch.randn((n, 1) + shape, generator=g) * scale
+    lobes = (torch.rand((n, 1) + shape, generator=g) > 0.4).float()
+    lobes.view(n, -1)[:, 0] = 1.0          # every sample has an inside ...
+    lobes.view(n, -1)[:, -1] = 0.0         # ... and an outside voxel
+    lesions = ((torch.rand((n, 1) + shape, generator=g) > 0.5) & (lobes > 0)).float()
+    images = torch.rand((n, 1) + shape, generator=g)
+    ctss = [float(i % 6) for i in range(n)]
+    d64 = dense.double().requires_grad_(True)
+    reg_r, seg_r = O.int_reg_refine_loss(d64, lobes.double(), lesions.double(), ctss, FREQ, 1e-2, 0.1)
+    (2.0 * reg_r + seg_r).backward()
+    batch = Batch(images.cuda(), lobes.cuda(), lesions.cuda(), ctss, FREQ, band_width=1e-2)
+    dg = dense.cuda().requires_grad_(True)
+    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dg, batch)
+    (2.0 * reg + seg).backward()
+    assert abs(reg.item() - reg_r.item()) <= 2e-5 * max(1.0, abs(reg_r.item()))
+    assert abs(seg.item() - seg_r.item()) <= 2e-5 * max(1.0, abs(seg_r.item()))
+    ref = d64.grad.float().numpy()
+    assert np.abs(dg.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    # deterministic: a second evaluation gives the same bits
+    reg2, seg2 = DeviceIntRegRefineLoss(1e-2, 0.1)(dg.detach(), batch)
+    assert reg2.item() == reg.item() and seg2.item() == seg.item()
+
+
+def test_trainer_step_matches_oracle(golden_dir):
+    """One optimisation step (forward, fused loss, backward, SGD) of the slim DC3D on the device,
+    whole batch and as two micro-batches of LayerNorm-free GroupNorm statistics ('ln' is per sample so
+    micro-batching does not change the math), against oracle forward + torch autograd on the CPU."""
+    import models
+    from dram_amd.train_step import Batch, DataParallelTrainer
+    z = np.load(os.path.join(golden_dir, "loss.npz"))
+    torch.manual_seed(5)
+    m = models.DC3D(**SLIM, norm_method="ln")
+    m.init(models.HeNorm(mode="fan_in"))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # oracle side, fp64
+    params, buffers = O.split_state_dict({k: v.double() for k, v in sd.items()})
+    for p in params.values():
+        p.requires_grad_(True)
+    t = lambda k: torch.from_numpy(z[k])
+    x = torch.zeros((6, 1, 16, 16, 16))
+    x[..., 2:14, 2:14, 2:14] = t("images")
+    lobes, lesions = torch.zeros_like(x), torch.zeros_like(x)
+    lobes[..., 2:14, 2:14, 2:14] = t("lobes")
+    lesions[..., 2:14, 2:14, 2:14] = t("lesions")
+    ctss = list(z["ctss"])
+    out = O.dc3d_forward(SLIM, params, buffers, x.double(), training=True, norm_method="ln")
+    dense = out[0] if isinstance(out, (tuple, list)) else out
+    reg_r, seg_r = O.int_reg_refine_loss(dense, lobes.double(), lesions.double(), ctss, FREQ, 1e-2, 0.1)
+    (2.0 * reg_r + seg_r).backward()
+    lr = 1e-3
+    expect = {k: (p.detach() - lr * p.grad).float() for k, p in params.items()}
+    for micro in (None, 3):
+        m.load_state_dict(sd)
+        mg = m.cuda().train()
+        tr = DataParallelTrainer(mg, torch.optim.SGD(mg.parameters(), lr=lr))
+        batch = Batch(x.cuda(), lobes.cuda(), lesions.cuda(), ctss, FREQ, band_width=1e-2)
+        reg, seg = tr.step(batch, micro_batch=micro)
+        assert abs(reg.item() - reg_r.item()) <= 1e-4 * max(1.0, abs(reg_r.item()))
+        if micro is None:   # seg is a whole-batch mean; micro-batching changes alpha (documented in train_step.py)
+            assert abs(seg.item() - seg_r.item()) <= 1e-4 * max(1.0, abs(seg_r.item()))
+            got = {k: v.detach().cpu() for k, v in mg.named_parameters()}
+            for k, e in expect.items():
+                step_ref = (e - sd[k]).abs().max().item()
+                err = (got[k] - e).abs().max().item()
+                assert err <= 2e-2 * step_ref + 1e-9, (k, err, step_ref)
+        m = m.cpu()
