@@ -490,3 +490,196 @@ def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", r
     mask = htp > th
     ratio = float((htp * lung).sum() / lung.sum())
     return htp, mask, th, ratio
+
+
+# --------------------------------------------------------------------------
+# PCM local attention + DC3DATGeneric (reference dram/models.py:150-597)
+#
+# PARITY UNPINNED at the PCM boundary: PCM.forward needs the real DGL (dgl.DGLGraph / update_all,
+# models.py:256-258,340), a third-party package that is absent from /root/reference and from this
+# image ("install 0.6.x", README.md:12; the Dockerfile builds git master).  The reference holds no
+# test or fixture for it.  What follows restates models.py:221-411 from reading it; `pcm_forward`
+# (dense, shifted views) and `pcm_forward_literal` (node by node, mailbox by mailbox, written to
+# mirror reduce_func / compute_cross_x line by line) are two independent restatements that are checked
+# against each other.  Everything of DC3DATGeneric around the PCM call *is* pinned by a golden vector
+# produced from the reference with `attention_module` swapped for a pass-through
+# (oracle/make_golden.py:gen_att).
+# --------------------------------------------------------------------------
+ST_DRAM_REF_ATT_MODEL = dict(ST_DRAM_REF_MODEL, **{     # dram/exp_settings/st_dram_ref_att.py:56-82
+    "at_spatial_size": (64, 64, 64), "at_f_dim": 8, "at_g_dim": 8, "at_g_iter": 1, "at_k_size": 3,
+    "at_merge_type": "scaled_dot_product_relu", "at_self_loop": False, "at_layers": [-1, 0, 1],
+    "at_p_enc_dim": 0, "at_geo_f_dim": 0,
+})
+
+PCM_DOT_MERGES = ("sm", "scaled_dot_product", "scaled_dot_product_relu", "smrelu", "smscaled", "l2sm", "l2smrelu")
+
+
+def pcm_offsets(k_size=3, connectivity=2, self_loop=True):
+    """Neighbour offsets of PCM.init_graph (models.py:230-232): the `connectivity` structuring element,
+    nearest-neighbour zoomed to k_size, relative to its centre; the centre is dropped when
+    self_loop is False (dgl.transform.remove_self_loop, models.py:257-258)."""
+    from scipy import ndimage
+    base = ndimage.generate_binary_structure(3, connectivity)
+    base = ndimage.zoom(base, k_size / 3.0, order=0)
+    off = np.asarray(np.where(base > 0)).T - np.asarray([k_size // 2] * 3)
+    if not self_loop:
+        off = off[np.any(off != 0, axis=1)]
+    return off.astype(np.int64)
+
+
+def _pcm_logits(merge_type, f, valid, deg):
+    """merge_func (models.py:259-331), dot-product family, on dense [B, E, ...] logits `f`; `valid`
+    marks real edges, `deg` = number of them (= f.shape[-1] of the reference's degree bucket)."""
+    ninf = torch.finfo(f.dtype).min
+    if merge_type in ("scaled_dot_product_relu", "smrelu", "l2smrelu"):
+        f = F.relu(f)
+    if merge_type in ("l2sm", "l2smrelu"):          # F.normalize(f, dim=-1): over the node's edges
+        nrm = torch.sqrt(((f * valid) ** 2).sum(1, keepdim=True)).clamp_min(1e-12)
+        f = f / nrm
+    if merge_type in ("scaled_dot_product", "scaled_dot_product_relu"):
+        f = f / torch.sqrt(deg)
+    if merge_type == "smscaled":
+        f = f / 0.01
+    f = torch.where(valid.bool().expand_as(f), f, torch.full_like(f, ninf))
+    return torch.softmax(f, dim=1)
+
+
+def _lin(p, name, x):
+    """nn.Linear over the channel axis of [B, C, ...]; Identity when the module has no weight."""
+    w = p.get(name + ".weight")
+    if w is None:
+        return x
+    y = torch.einsum("bc...,fc->bf...", x, w)
+    return y + p[name + ".bias"].view(1, -1, *([1] * (x.dim() - 2)))
+
+
+def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type="scaled_dot_product_relu",
+                non_local_iter=1, residual=False):
+    """PCM.forward (models.py:333-363) with p_enc_dim == 0, as dense tensor algebra.
+    p: {"theta.weight", "theta.bias", "phi.*", "G.*", "r.*"} (absent = Identity, models.py:169-183).
+    cam [B, g_ch, D, H, W], f [B, in_ch, D, H, W] -> refined cam [B, g_ch, D, H, W]."""
+    if merge_type not in PCM_DOT_MERGES:
+        raise NotImplementedError(merge_type)
+    B, _, D, H, W = f.shape
+    offs = pcm_offsets(k_size, connectivity, self_loop)
+    R = int(np.abs(offs).max()) if len(offs) else 0
+    th, ph = _lin(p, "theta", f), _lin(p, "phi", f)
+    ones = torch.ones((1, 1, D, H, W), dtype=f.dtype)
+
+    def shifted(t, o):      # t at node + o, zero outside the grid
+        tp = F.pad(t, (R, R, R, R, R, R))
+        return tp[..., R + o[0]:R + o[0] + D, R + o[1]:R + o[1] + H, R + o[2]:R + o[2] + W]
+    valid = torch.cat([shifted(ones, o) for o in offs], dim=1)              # [1, E, D, H, W]
+    deg = valid.sum(1, keepdim=True)
+    logits = torch.stack([(th * shifted(ph, o)).sum(1) for o in offs], dim=1)   # [B, E, D, H, W]
+    a = _pcm_logits(merge_type, logits, valid, deg)
+    for _ in range(non_local_iter):
+        g = _lin(p, "G", cam)                                                # [B, g_dim, D, H, W]
+        y = sum(a[:, e:e + 1] * shifted(g, o) for e, o in enumerate(offs))
+        refined = _lin(p, "r", y)
+        cam = refined + cam if residual else refined
+    return cam
+
+
+def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
+                        merge_type="scaled_dot_product_relu"):
+    """The same, written the way DGL executes it: one node at a time, its mailbox = the in-grid
+    neighbours (init_graph's interior/side split collapses to "neighbours inside the grid"),
+    compute_cross_x's permutes and matmuls spelled out (models.py:365-397).  Tiny grids only."""
+    B, C, D, H, W = f.shape
+    offs = pcm_offsets(k_size, connectivity, self_loop)
+    out = torch.zeros_like(cam)
+    lin = lambda name, x: x if (name + ".weight") not in p else F.linear(x, p[name + ".weight"], p[name + ".bias"])
+    for z in range(D):
+        for y in range(H):
+            for x in range(W):
+                nb = [(z + o[0], y + o[1], x + o[2]) for o in offs]
+                nb = [q for q in nb if 0 <= q[0] < D and 0 <= q[1] < H and 0 <= q[2] < W]
+                f_agg = torch.stack([f[:, :, q[0], q[1], q[2]] for q in nb], 0)          # [E, B, C]
+                cam_agg = torch.stack([cam[:, :, q[0], q[1], q[2]] for q in nb], 0)      # [E, B, g_ch]
+                x_phi = lin("phi", f_agg).permute(1, 2, 0)                                # [B, F, E]
+                x_theta = lin("theta", f[:, :, z, y, x]).unsqueeze(1)                     # [B, 1, F]
+                fm = torch.matmul(x_theta, x_phi)                                         # [B, 1, E]
+                if merge_type in ("scaled_dot_product_relu", "smrelu", "l2smrelu"):
+                    fm = F.relu(fm)
+                if merge_type in ("l2sm", "l2smrelu"):
+                    fm = F.normalize(fm, dim=-1)
+                if merge_type in ("scaled_dot_product", "scaled_dot_product_relu"):
+                    fm = fm / np.sqrt(fm.shape[-1])
+                if merge_type == "smscaled":
+                    fm = fm / 0.01
+                f_sm = F.softmax(fm, dim=-1)
+                x_g = lin("G", cam_agg).permute(1, 0, 2)                                  # [B, E, g_dim]
+                yv = torch.matmul(f_sm, x_g).squeeze(1)                                   # [B, g_dim]
+                out[:, :, z, y, x] = lin("r", yv)
+    return out
+
+
+def dc3dat_forward(cfg, params, buffers, x, training=False, norm_method="bn", attention=True):
+    """DC3DATGeneric.forward (models.py:543-597) + apply_attention (498-506) for `cfg` (a MODEL dict
+    of st_dram_ref_att.py without 'method').  Returns (dense_outs, refined_dense_outs, attention_features).  Blocks are run
+    without torch.utils.checkpoint (use for values/gradients; the checkpoint double update of
+    BatchNorm buffers is a DC3D-level effect covered by dc3d_forward).  attention=False replaces the
+    PCM by a pass-through (what the golden vector pins)."""
+    L = cfg["n_layers"]
+    at_layers = list(cfg["at_layers"])
+    at_size = tuple(cfg["at_spatial_size"])
+    feats, att = [], ([x] if -1 in at_layers else [])
+    nc = 0
+
+    def reshape(t):
+        nonlocal nc
+        pfx = f"reshape.{nc}"
+        nc += 1
+        y = conv3d(t.detach(), params[pfx + ".0.weight"], params[pfx + ".0.bias"], 0)
+        rm, rv = buffers[pfx + ".1.running_mean"], buffers[pfx + ".1.running_var"]
+        if training:
+            buffers[pfx + ".1.num_batches_tracked"] += 1
+        y = F.batch_norm(y, rm, rv, params[pfx + ".1.weight"], params[pfx + ".1.bias"], training, BN_MOMENTUM, EPS)
+        return F.relu(y)
+
+    cur = x
+    for n in range(L):
+        y = conv_norm_act_stack(f"ds_modules.{n}", 2, params, buffers, cur, norm_method, training, _pads(cfg, n))
+        cur = max_pool3d_2(y)
+        feats.append(y)
+        if n in at_layers:
+            att.append(reshape(y))
+    cur = conv_norm_act_stack("bg", 2, params, buffers, cur, norm_method, training, _pads(cfg, L))
+    if L in at_layers:
+        att.append(reshape(cur))
+    for idx, skip in enumerate(reversed(feats)):
+        if cfg.get("stacking", 0) == idx:
+            break
+        up = upsample_trilinear_ac(cur, scale_factor=tuple(cfg["upsample_sf"])
+                                   if isinstance(cfg["upsample_sf"], (tuple, list)) else cfg["upsample_sf"])
+        cur = conv_norm_act_stack(f"us_modules.{idx}", 2, params, buffers, crop_concat_5d(up, skip), norm_method,
+                                  training, _pads(cfg, L + 1 + idx))
+        if L + idx + 1 in at_layers:
+            att.append(reshape(cur))
+    dense = conv3d(cur, params["top_layer.weight"], params["top_layer.bias"], 0)
+    dense = upsample_trilinear_ac(dense, size=tuple(x.shape[-3:]))
+    att = torch.cat([upsample_trilinear_ac(t, size=at_size) for t in att], dim=1)
+    cam = upsample_trilinear_ac(dense, size=at_size)
+    if attention:
+        pp = {k[len("attention_module."):]: v for k, v in params.items() if k.startswith("attention_module.")}
+        cam = pcm_forward(pp, cam, att, cfg["at_k_size"], 2, cfg["at_self_loop"], cfg["at_merge_type"],
+                          cfg["at_g_iter"], False)
+    refined = upsample_trilinear_ac(cam, size=tuple(dense.shape[2:]))
+    return dense, refined, att
+
+
+def int_reg_refine_loss2(dense, refined, lobes, lesions, ctsses, freq_map, band_width=1e-2, smoothing=0.1):
+    """IntRegRefineLoss.__call__ (metrics.py:360-373) for a model with distinct outputs
+    (DC3DATGeneric): regression term and pseudo label from `dense`, segmentation term on `refined`."""
+    probs = torch.sigmoid(dense)
+    reg = reg_loss_with_probs(probs, lobes, lesions, ctsses, freq_map, band_width)
+    with torch.no_grad():
+        pd = probs.detach().clone()
+        pd[lobes == 0] = 0.0
+        pseudo = ((pd > 0.5) & (lesions > 0)).to(dense.dtype)
+        keep = torch.tensor([0.0 if float(c) < 1e-7 else 1.0 for c in ctsses], dtype=dense.dtype,
+                            device=dense.device).view(-1, 1, 1, 1, 1)
+        pseudo = pseudo * keep
+    seg = boot_bce(torch.sigmoid(refined), pseudo, lobes > 0, smoothing)
+    return reg, seg

@@ -241,9 +241,93 @@ def gen_loss():
     _save("loss", **arrs)
 
 
+SLIM_ATT = dict(SLIM, at_spatial_size=(6, 5, 7), at_f_dim=4, at_g_dim=3, at_g_iter=1, at_k_size=3,
+                at_merge_type="scaled_dot_product_relu", at_self_loop=False, at_layers=[-1, 0, 1],
+                at_p_enc_dim=0, at_geo_f_dim=0)
+
+
+def gen_att(models):
+    """DC3DATGeneric (models.py:413-597) with everything of the reference run as is except the PCM
+    (needs DGL, absent): `attention_module` is swapped for a pass-through that records its inputs.
+    Pins the wiring around the attention (reshape convs on detached features, resizes, concat order,
+    the two outputs) and the state-dict keys / init of the full module incl. PCM's Linear layers."""
+    arrs = {}
+    tag = "slim_att"
+    torch.manual_seed(0)
+    model = models.DC3DATGeneric(**SLIM_ATT)
+    model.init(models.HeNorm(mode="fan_in"))
+    for k, v in model.state_dict().items():
+        arrs[f"{tag}/sd/{k}"] = _np(v)
+
+    class PassThrough(torch.nn.Module):
+        def forward(self, cam, feats, args=None):
+            self.seen = (cam, feats)
+            return cam
+    model.attention_module = PassThrough()
+    x = torch.rand((2, 1, 16, 16, 16), generator=torch.Generator().manual_seed(1))
+    arrs[f"{tag}/x"] = _np(x)
+    model.train()
+    d0, d1 = model(x, None)
+    cam, feats = model.attention_module.seen
+    arrs[f"{tag}/dense"], arrs[f"{tag}/refined"] = _np(d0), _np(d1)
+    arrs[f"{tag}/cam"], arrs[f"{tag}/feats"] = _np(cam), _np(feats)
+    g = torch.Generator().manual_seed(2)
+    g0 = torch.randn(d0.shape, generator=g) / d0.numel()
+    g1 = torch.randn(d1.shape, generator=g) / d1.numel()
+    gf = torch.randn(feats.shape, generator=g) / feats.numel()
+    arrs[f"{tag}/gout0"], arrs[f"{tag}/gout1"], arrs[f"{tag}/goutf"] = _np(g0), _np(g1), _np(gf)
+    ((d0 * g0).sum() + (d1 * g1).sum() + (feats * gf).sum()).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            arrs[f"{tag}/grad/{k}"] = _np(p.grad)
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrs[f"{tag}/sd_after/{k}"] = _np(v)
+    _save("dc3dat_slim", **arrs)
+
+
+def gen_loss2():
+    """IntRegRefineLoss for a model whose two outputs differ (DC3DATGeneric)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self     # generator process only (metrics.py:136,173)
+    import metrics
+
+    class Obj:
+        ctss_frequency_map = {k: 1.0 / 6 for k in range(6)}
+        debug_path = "/tmp/_dram_golden_dbg"
+        epoch_n = 0
+    g = torch.Generator().manual_seed(78)
+    N, S = 6, 12
+    zz, yy, xx = np.meshgrid(*[np.arange(S)] * 3, indexing="ij")
+    lobe = (((zz - S / 2 + .5) ** 2 + (yy - S / 2 + .5) ** 2 + (xx - S / 2 + .5) ** 2) < (0.45 * S) ** 2)
+    lobes = torch.from_numpy(lobe.astype(np.float32))[None, None].repeat(N, 1, 1, 1, 1)
+    images = torch.rand(N, 1, S, S, S, generator=g) * lobes
+    lesions = ((images > 0.7) & (lobes > 0)).float()
+    ctss = [float(n % 6) for n in range(N)]
+    dense = (torch.randn(N, 1, S, S, S, generator=g) * 2.0).requires_grad_(True)
+    refined = (torch.randn(N, 1, S, S, S, generator=g) * 2.0).requires_grad_(True)
+    loss_fn = metrics.IntRegRefineLoss(band_width=1e-2, smoothing=0.1)
+
+    def fake_model(imgs, lbs):
+        return dense, refined
+    fake_model.trace_path = None
+    reg, seg = loss_fn(fake_model, images, lobes, lesions, ctss, obj=Obj(), metas=None)
+    (2.0 * reg + 1.0 * seg).backward()
+    _save("loss2", images=_np(images), lobes=_np(lobes), lesions=_np(lesions), ctss=np.array(ctss),
+          dense=_np(dense), refined=_np(refined), reg=np.array(reg.item()), seg=np.array(seg.item()),
+          gdense=_np(dense.grad), grefined=_np(refined.grad))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     parts, models = _import_reference()
-    gen_blocks(parts)
-    gen_models(models)
-    gen_loss()
+    only = set(sys.argv[1:])          # e.g. `python oracle/make_golden.py att loss2`; default: everything
+    if not only or "blocks" in only:
+        gen_blocks(parts)
+    if not only or "models" in only:
+        gen_models(models)
+    if not only or "att" in only:
+        gen_att(models)
+    if not only or "loss" in only:
+        gen_loss()
+    if not only or "loss2" in only:
+        gen_loss2()

@@ -138,3 +138,62 @@ def test_loss(golden_dir):
     assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
     (2.0 * reg + 1.0 * seg).backward()
     _close(dense.grad, z["gdense"], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------- N2: DC3DATGeneric / PCM
+def test_dc3dat_wiring_matches_reference_golden(golden_dir):
+    """Everything of DC3DATGeneric around the PCM call, against the reference run with a pass-through
+    attention module (oracle/make_golden.py:gen_att)."""
+    from oracle.make_golden import SLIM_ATT
+    z = _load(golden_dir, "dc3dat_slim")
+    tag = "slim_att"
+    params, buffers = O.split_state_dict({k: _t(v) for k, v in _sub(z, tag + "/sd/").items()})
+    for p in params.values():
+        p.requires_grad_(True)
+    x = _t(z[tag + "/x"])
+    dense, refined, feats = O.dc3dat_forward(SLIM_ATT, params, buffers, x, training=True, attention=False)
+    _close(dense, z[tag + "/dense"], rtol=1e-4, atol=1e-5)
+    _close(refined, z[tag + "/refined"], rtol=1e-4, atol=1e-5)
+    _close(feats, z[tag + "/feats"], rtol=1e-4, atol=1e-5)
+    ((dense * _t(z[tag + "/gout0"])).sum() + (refined * _t(z[tag + "/gout1"])).sum()
+     + (feats * _t(z[tag + "/goutf"])).sum()).backward()
+    grads = _sub(z, tag + "/grad/")
+    assert any(k.startswith("reshape.") for k in grads) and not any(k.startswith("attention_module") for k in grads)
+    for k, g in grads.items():
+        _close(params[k].grad, g, rtol=2e-3, atol=1e-4 * max(1e-3, float(np.abs(g).max())))
+    for k, v in _sub(z, tag + "/sd_after/").items():
+        if "num_batches" in k:   # the oracle runs flagged blocks once (no checkpoint re-run)
+            continue
+        if k.startswith("reshape."):
+            _close(buffers[k].double(), v.astype(np.float64), rtol=1e-5, atol=1e-6)
+    # PCM's parameters exist under the reference's names and shapes
+    assert params["attention_module.theta.weight"].shape == (4, 9) and params["attention_module.G.weight"].shape == (3, 1)
+    assert params["attention_module.r.weight"].shape == (1, 3) and params["attention_module.phi.bias"].shape == (4,)
+
+
+@pytest.mark.parametrize("merge", O.PCM_DOT_MERGES)
+@pytest.mark.parametrize("self_loop", [False, True])
+def test_pcm_dense_restatement_equals_literal_one(merge, self_loop):
+    """PARITY UNPINNED (DGL absent): two independent restatements of PCM agree with each other."""
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    p = {"theta.weight": r(4, 5), "theta.bias": r(4), "phi.weight": r(4, 5), "phi.bias": r(4),
+         "G.weight": r(3, 2), "G.bias": r(3), "r.weight": r(2, 3), "r.bias": r(2)}
+    for shape in [(4, 3, 5), (1, 2, 3)]:
+        cam, f = r(2, 2, *shape), r(2, 5, *shape)
+        a = O.pcm_forward(p, cam, f, 3, 2, self_loop, merge)
+        b = O.pcm_forward_literal(p, cam, f, 3, 2, self_loop, merge)
+        assert (a - b).abs().max().item() < 1e-10
+    assert len(O.pcm_offsets(3, 2, False)) == 18 and len(O.pcm_offsets(3, 1, True)) == 7   # st_dram_ref_att: 18
+
+
+def test_loss_two_outputs(golden_dir):
+    z = _load(golden_dir, "loss2")
+    dense, refined = _t(z["dense"]).requires_grad_(True), _t(z["refined"]).requires_grad_(True)
+    freq = {k: 1.0 / 6 for k in range(6)}
+    reg, seg = O.int_reg_refine_loss2(dense, refined, _t(z["lobes"]), _t(z["lesions"]), list(z["ctss"]), freq, 1e-2, 0.1)
+    assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
+    assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
+    (2.0 * reg + 1.0 * seg).backward()
+    _close(dense.grad, z["gdense"], rtol=1e-4, atol=1e-6)
+    _close(refined.grad, z["grefined"], rtol=1e-4, atol=1e-6)
