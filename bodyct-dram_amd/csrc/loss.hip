@@ -4,9 +4,9 @@
 // of the reference's training loss, dram/metrics.py: IntRegLoss.compute_reg_loss_with_probs (158-177),
 // IntRegRefineLoss.compute_seg_loss (331-358) with BootBinCrossEntropy (17-51), __call__ (360-373).
 //
-//   p      = sigmoid(dense)
-//   reg    = sum_n max((r_n - c_n)^2 - K_n, 0) / w_n,   r_n = sum_v p m / sum_v m   (m = lobe mask)
-//   t      = [p > 0.5] [m] [lesion > 0] keep_n           (pseudo label, no gradient)
+//   p      = sigmoid(refined), pd = sigmoid(dense)   (DC3D: refined is dense; DC3DATGeneric: the PCM output)
+//   reg    = sum_n max((r_n - c_n)^2 - K_n, 0) / w_n,   r_n = sum_v pd m / sum_v m   (m = lobe mask)
+//   t      = [pd > 0.5] [m] [lesion > 0] keep_n          (pseudo label, no gradient)
 //   seg    = mean_{m=0} -log(1-p)  +  (1-s) * (alpha A + (1-alpha) B) / (alpha T + (1-alpha)(n_in - T))  +  s * mean_{m=1} -log(max(p,1-p))
 //            A = sum_{t=1} -log p,  B = sum_{m=1,t=0} -log(1-p),  T = sum t,  alpha = clamp(1 - T/n_in, .25, .75)
 //            (all logs of values clamped to [eps, 1-eps], eps = 1e-7, as torch.clamp: zero gradient outside)
@@ -31,7 +31,8 @@ __device__ __forceinline__ void sigmoid_pq(float d, float& p, float& q) {
 }
 __device__ __forceinline__ float nlog_clamped(float v) { return -logf(fminf(fmaxf(v, LEPS), 1.f - LEPS)); }
 
-__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ dense, const float* __restrict__ lobes,
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ dense, const float* __restrict__ refined,
+                                                           const float* __restrict__ lobes,
                                                            const float* __restrict__ lesions, const float* __restrict__ keep,
                                                            float* __restrict__ part, int64_t S, int nchunks) {
     __shared__ float red[4];
@@ -40,17 +41,22 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
     const int len = (int)((S - beg) < LCHUNK ? (S - beg) : LCHUNK);
     const float kp = keep[n];
     const float* pd = dense + (int64_t)n * S + beg;
+    const float* pr = refined + (int64_t)n * S + beg;
+    const bool same = dense == refined;
     const float* pm = lobes + (int64_t)n * S + beg;
     const float* pl = lesions + (int64_t)n * S + beg;
     float acc[NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int e = threadIdx.x; e < len; e += 256) {
-        float p, q;
-        sigmoid_pq(pd[e], p, q);
+        float p, q, pden, qden;
+        const float dv = pd[e];
+        sigmoid_pq(dv, pden, qden);
+        if (same) { p = pden; q = qden; }
+        else sigmoid_pq(pr[e], p, q);
         const bool in = pm[e] > 0.f;
         if (in) {
-            acc[0] += p;
+            acc[0] += pden;
             acc[1] += 1.f;
-            const bool t = (p > 0.5f) && (pl[e] > 0.f) && (kp > 0.f);
+            const bool t = (pden > 0.5f) && (pl[e] > 0.f) && (kp > 0.f);
             if (t) { acc[4] += 1.f; acc[5] += nlog_clamped(p); }
             else acc[6] += nlog_clamped(q);
             acc[7] += nlog_clamped(fmaxf(p, q));
@@ -111,11 +117,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 }
 
 // d(g0*reg + g1*seg)/d dense
-__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ dense, const float* __restrict__ lobes,
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ dense, const float* __restrict__ refined,
+                                                       const float* __restrict__ lobes,
                                                        const float* __restrict__ lesions, const float* __restrict__ keep,
                                                        const float* __restrict__ targets, const float* __restrict__ weight,
                                                        const float* __restrict__ state, const float* __restrict__ gout,
-                                                       float smoothing, float* __restrict__ ddense, int64_t S) {
+                                                       float smoothing, float* __restrict__ ddense,
+                                                       float* __restrict__ drefined, int64_t S) {
     const int n = blockIdx.y;
     const float g0 = gout[0], g1 = gout[1];
     const float alpha = state[0], wsum = state[1], n_in = state[2], n_out = state[3];
@@ -132,20 +140,28 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < S; e += stride) {
         const int64_t o = (int64_t)n * S + e;
-        float p, q;
-        sigmoid_pq(dense[o], p, q);
+        float p, q, pden, qden;
+        sigmoid_pq(dense[o], pden, qden);
+        if (drefined) sigmoid_pq(refined[o], p, q);
+        else { p = pden; q = qden; }
         // d(-log(clamp(v)))/dv = -1/v inside [eps, 1-eps], 0 outside; p in [eps, 1-eps] <=> q in [eps, 1-eps]
         const bool live = p >= LEPS && q >= LEPS;
         const float dlp = live ? -1.f / p : 0.f;      // of -log p      w.r.t. p
         const float dlq = live ? 1.f / q : 0.f;       // of -log(1-p)   w.r.t. p
-        float gp;
+        float gseg, gr = 0.f;
         if (lobes[o] > 0.f) {
-            const bool t = (p > 0.5f) && (lesions[o] > 0.f) && (kp > 0.f);
-            gp = greg + (t ? c_a * dlp : c_b * dlq) + c_boot * (p > 0.5f ? dlp : dlq);
+            const bool t = (pden > 0.5f) && (lesions[o] > 0.f) && (kp > 0.f);
+            gr = greg;
+            gseg = (t ? c_a * dlp : c_b * dlq) + c_boot * (p > 0.5f ? dlp : dlq);
         } else {
-            gp = c_out * dlq;
+            gseg = c_out * dlq;
         }
-        ddense[o] = gp * p * q;
+        if (drefined) {
+            ddense[o] = gr * pden * qden;
+            drefined[o] = gseg * p * q;
+        } else {
+            ddense[o] = (gr + gseg) * p * q;
+        }
     }
 }
 
@@ -162,9 +178,10 @@ extern "C" size_t dram_intreg_loss_ws_bytes(int N, int64_t S) {
 
 extern "C" int dram_intreg_loss_state_floats(int N) { return 4 + 2 * (N > 0 ? N : 0); }
 
-extern "C" int dram_intreg_loss_fwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
-                                    const float* targets, const float* weight, float smoothing, float* out,
-                                    float* state, void* ws, size_t ws_bytes, int N, int64_t S, void* stream) {
+extern "C" int dram_intreg_loss_fwd(const float* dense, const float* refined, const float* lobes, const float* lesions,
+                                    const float* keep, const float* targets, const float* weight, float smoothing,
+                                    float* out, float* state, void* ws, size_t ws_bytes, int N, int64_t S, void* stream) {
+    if (!refined) refined = dense;
     DRAM_REQUIRE(dense && lobes && lesions && keep && targets && weight && out && state && ws, "intreg_loss_fwd: null pointer");
     DRAM_REQUIRE(N > 0 && N <= 65535 && S > 0, "intreg_loss_fwd: bad dimensions");
     if (ws_bytes < dram_intreg_loss_ws_bytes(N, S)) {
@@ -173,19 +190,22 @@ extern "C" int dram_intreg_loss_fwd(const float* dense, const float* lobes, cons
     }
     hipStream_t st = (hipStream_t)stream;
     const int nch = loss_chunks(S);
-    hipLaunchKernelGGL(loss_partial_kernel, dim3(nch, N), dim3(256), 0, st, dense, lobes, lesions, keep, (float*)ws, S, nch);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nch, N), dim3(256), 0, st, dense, refined, lobes, lesions, keep, (float*)ws, S, nch);
     double* ssum = (double*)((char*)ws + align_up((size_t)N * nch * NSUM * sizeof(float), 256));
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, ssum, targets, weight, smoothing, N, nch, out, state);
     return check_launch("intreg_loss_fwd");
 }
 
-extern "C" int dram_intreg_loss_bwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
-                                    const float* targets, const float* weight, const float* state, const float* gout,
-                                    float smoothing, float* ddense, int N, int64_t S, void* stream) {
+extern "C" int dram_intreg_loss_bwd(const float* dense, const float* refined, const float* lobes, const float* lesions,
+                                    const float* keep, const float* targets, const float* weight, const float* state,
+                                    const float* gout, float smoothing, float* ddense, float* drefined, int N, int64_t S,
+                                    void* stream) {
+    if (!refined || refined == dense) { refined = dense; drefined = nullptr; }
+    else DRAM_REQUIRE(drefined, "intreg_loss_bwd: drefined is required when refined differs from dense");
     DRAM_REQUIRE(dense && lobes && lesions && keep && targets && weight && state && gout && ddense, "intreg_loss_bwd: null pointer");
     DRAM_REQUIRE(N > 0 && N <= 65535 && S > 0, "intreg_loss_bwd: bad dimensions");
     const unsigned gx = (unsigned)(cdiv64(S, 256 * 8) < 4096 ? cdiv64(S, 256 * 8) : 4096);
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx ? gx : 1, N), dim3(256), 0, (hipStream_t)stream, dense, lobes, lesions, keep,
-                       targets, weight, state, gout, smoothing, ddense, S);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx ? gx : 1, N), dim3(256), 0, (hipStream_t)stream, dense, refined, lobes, lesions,
+                       keep, targets, weight, state, gout, smoothing, ddense, drefined, S);
     return check_launch("intreg_loss_bwd");
 }

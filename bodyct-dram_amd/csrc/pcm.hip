@@ -1,0 +1,300 @@
+// PCM local attention on a regular voxel grid, gfx950.
+//
+// Replaces the reference's graph formulation, dram/models.py: PCM.init_graph (221-258: a networkx
+// DiGraph with one edge per (neighbour -> node) pair, ~4.7 M edges for 64^3 x 18, turned into a
+// dgl.DGLGraph), PCM.forward's g.update_all (333-363), message_func / reduce_func (399-411) and
+// compute_cross_x + merge_func (259-331, 365-397).  On a grid the graph is a stencil: node i receives
+// from i + o_e for the E offsets of the structuring element (in-grid ones only), so
+//
+//   a[b,e,i]   = softmax_e( s(deg_i) * n_i( act( sum_f theta[b,f,i] * phi[b,f,i+o_e] ) ) )      (attention)
+//   out[b,c,i] = sum_e a[b,e,i] * v[b,c,i+o_e]                                                   (aggregate)
+//
+// with act = identity | ReLU, n_i = identity | L2 normalisation over the node's edges, s = 1 |
+// 1/sqrt(#edges of the node) | 1/0.01 -- the dot-product family of merge_func.  theta, phi, v and the
+// result are NCDHW planes; the attention weights are kept as E planes [B,E,S] (saved for the backward
+// and re-used by every non_local_iter).  HBM-bound stencil work, one thread per node along x;
+// every reduction is a gather (no atomics), so results are deterministic.
+#include "common.h"
+
+namespace dram {
+
+constexpr int PCM_MAXE = 128;
+constexpr float PCM_L2EPS = 1e-12f;     // F.normalize's eps
+
+struct PcmOffsets {
+    int n;
+    signed char dz[PCM_MAXE], dy[PCM_MAXE], dx[PCM_MAXE];
+};
+
+struct PcmGrid {
+    int D, H, W;
+    int64_t S;
+};
+
+enum { PCM_RELU = 1, PCM_L2NORM = 2 };
+enum { PCM_SCALE_NONE = 0, PCM_SCALE_RSQRT_DEG = 1, PCM_SCALE_100 = 2 };
+
+__device__ __forceinline__ bool pcm_neighbour(const PcmGrid& g, const PcmOffsets& o, int e, int z, int y, int x, int64_t i,
+                                              int64_t& j) {
+    const int zz = z + o.dz[e], yy = y + o.dy[e], xx = x + o.dx[e];
+    j = i + ((int64_t)o.dz[e] * g.H + o.dy[e]) * g.W + o.dx[e];
+    return (unsigned)zz < (unsigned)g.D && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+}
+
+__device__ __forceinline__ float pcm_scale(int scale_mode, float deg) {
+    return scale_mode == PCM_SCALE_RSQRT_DEG ? 1.f / sqrtf(deg) : (scale_mode == PCM_SCALE_100 ? 100.f : 1.f);
+}
+
+// ---------------------------------------------------------------- attention weights
+__global__ __launch_bounds__(256) void pcm_attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                           float* __restrict__ attn, PcmOffsets o, PcmGrid g, int F,
+                                                           int flags, int scale_mode) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* th = theta + (int64_t)b * F * g.S + i;
+    const float* ph = phi + (int64_t)b * F * g.S;
+    float* a = attn + (int64_t)b * o.n * g.S + i;
+    // pass A: activated dot products u_e (parked in the output planes), degree, max, sum of squares
+    float deg = 0.f, umax = -INFINITY, ss = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float u = 0.f;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
+            for (int f = 0; f < F; ++f) u = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], u);
+            if (flags & PCM_RELU) u = fmaxf(u, 0.f);
+            deg += 1.f;
+            umax = fmaxf(umax, u);
+            ss = fmaf(u, u, ss);
+            a[(int64_t)e * g.S] = u;
+        } else {
+            a[(int64_t)e * g.S] = -INFINITY;        // not an edge
+        }
+    }
+    if (deg == 0.f) {                                // isolated node (1x1x1 grid without self loop): no messages
+        for (int e = 0; e < o.n; ++e) a[(int64_t)e * g.S] = 0.f;
+        return;
+    }
+    float c = pcm_scale(scale_mode, deg);
+    if (flags & PCM_L2NORM) c /= fmaxf(sqrtf(ss), PCM_L2EPS);
+    // pass B: exponentials (c > 0, so the largest logit is c * umax)
+    float sum = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        const float u = a[(int64_t)e * g.S];
+        const float w = u == -INFINITY ? 0.f : expf(c * (u - umax));
+        sum += w;
+        a[(int64_t)e * g.S] = w;
+    }
+    const float inv = 1.f / sum;
+    for (int e = 0; e < o.n; ++e) a[(int64_t)e * g.S] *= inv;
+}
+
+// dlogit (gradient w.r.t. the raw dot products) from dattn; dtheta from it.  ds has the layout of attn.
+__global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                           const float* __restrict__ attn, const float* __restrict__ dattn,
+                                                           float* __restrict__ ds, float* __restrict__ dtheta, PcmOffsets o,
+                                                           PcmGrid g, int F, int flags, int scale_mode) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* th = theta + (int64_t)b * F * g.S + i;
+    const float* ph = phi + (int64_t)b * F * g.S;
+    const float* a = attn + (int64_t)b * o.n * g.S + i;
+    const float* da = dattn + (int64_t)b * o.n * g.S + i;
+    float* s = ds + (int64_t)b * o.n * g.S + i;
+    // pass A: recompute the raw dots (parked in ds), sum_k a_k da_k, degree, sum of squares of the activated dots
+    float deg = 0.f, ada = 0.f, ss = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float dot = 0.f;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
+            for (int f = 0; f < F; ++f) dot = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], dot);
+            deg += 1.f;
+            const float u = (flags & PCM_RELU) ? fmaxf(dot, 0.f) : dot;
+            ss = fmaf(u, u, ss);
+            ada = fmaf(a[(int64_t)e * g.S], da[(int64_t)e * g.S], ada);
+        }
+        s[(int64_t)e * g.S] = dot;
+    }
+    const float scale = deg > 0.f ? pcm_scale(scale_mode, deg) : 0.f;
+    const float nrm = fmaxf(sqrtf(ss), PCM_L2EPS);
+    const bool l2 = flags & PCM_L2NORM, l2live = sqrtf(ss) > PCM_L2EPS;
+    // pass B (L2 only): sum_k v_k dv_k with v = u / nrm, dv = scale * dlogit
+    float vdv = 0.f;
+    if (l2 && l2live) {
+        for (int e = 0; e < o.n; ++e) {
+            int64_t j;
+            if (!pcm_neighbour(g, o, e, z, y, x, i, j)) continue;
+            const float dot = s[(int64_t)e * g.S];
+            const float u = (flags & PCM_RELU) ? fmaxf(dot, 0.f) : dot;
+            const float ae = a[(int64_t)e * g.S];
+            vdv = fmaf(u / nrm, scale * ae * (da[(int64_t)e * g.S] - ada), vdv);
+        }
+    }
+    // pass C: gradient w.r.t. the raw dot of every edge
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float d = 0.f;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
+            const float dot = s[(int64_t)e * g.S];
+            const float u = (flags & PCM_RELU) ? fmaxf(dot, 0.f) : dot;
+            const float ae = a[(int64_t)e * g.S];
+            const float dl = scale * ae * (da[(int64_t)e * g.S] - ada);      // w.r.t. the normalised, unscaled logit
+            d = l2 ? (l2live ? (dl - (u / nrm) * vdv) / nrm : dl / nrm) : dl;
+            if ((flags & PCM_RELU) && !(dot > 0.f)) d = 0.f;
+        }
+        s[(int64_t)e * g.S] = d;
+    }
+    // dtheta[b,f,i] = sum_e ds_e * phi[b,f,i+o_e]
+    float* dth = dtheta + (int64_t)b * F * g.S + i;
+    for (int f = 0; f < F; ++f) {
+        float acc = 0.f;
+        for (int e = 0; e < o.n; ++e) {
+            int64_t j;
+            if (pcm_neighbour(g, o, e, z, y, x, i, j)) acc = fmaf(s[(int64_t)e * g.S], ph[(int64_t)f * g.S + j], acc);
+        }
+        dth[(int64_t)f * g.S] = acc;
+    }
+}
+
+// Adjoint gather shared by dphi and dv:  out[b,c,j] = sum_e w[b,e,j-o_e] * src[b,c,j-o_e]  (j - o_e inside the grid)
+__global__ __launch_bounds__(256) void pcm_scatter_adjoint_kernel(const float* __restrict__ w, const float* __restrict__ src,
+                                                                  float* __restrict__ out, PcmOffsets o, PcmGrid g, int C) {
+    const int64_t jn = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (jn >= g.S) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int x = (int)(jn % g.W), y = (int)((jn / g.W) % g.H), z = (int)(jn / ((int64_t)g.W * g.H));
+    const float* wb = w + (int64_t)b * o.n * g.S;
+    const float* sb = src + ((int64_t)b * C + c) * g.S;
+    float acc = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        const int zz = z - o.dz[e], yy = y - o.dy[e], xx = x - o.dx[e];
+        if ((unsigned)zz < (unsigned)g.D && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
+            const int64_t i = jn - (((int64_t)o.dz[e] * g.H + o.dy[e]) * g.W + o.dx[e]);
+            acc = fmaf(wb[(int64_t)e * g.S + i], sb[i], acc);
+        }
+    }
+    out[((int64_t)b * C + c) * g.S + jn] = acc;
+}
+
+// ---------------------------------------------------------------- aggregation
+__global__ __launch_bounds__(256) void pcm_aggregate_fwd_kernel(const float* __restrict__ attn, const float* __restrict__ v,
+                                                                float* __restrict__ out, PcmOffsets o, PcmGrid g, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* a = attn + (int64_t)b * o.n * g.S + i;
+    const float* vb = v + ((int64_t)b * C + c) * g.S;
+    float acc = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) acc = fmaf(a[(int64_t)e * g.S], vb[j], acc);
+    }
+    out[((int64_t)b * C + c) * g.S + i] = acc;
+}
+
+// dattn[b,e,i] = sum_c dout[b,c,i] * v[b,c,i+o_e]
+__global__ __launch_bounds__(256) void pcm_aggregate_dattn_kernel(const float* __restrict__ dout, const float* __restrict__ v,
+                                                                  float* __restrict__ dattn, PcmOffsets o, PcmGrid g, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* d = dout + (int64_t)b * C * g.S + i;
+    const float* vb = v + (int64_t)b * C * g.S;
+    float* da = dattn + (int64_t)b * o.n * g.S + i;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float acc = 0.f;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j))
+            for (int c = 0; c < C; ++c) acc = fmaf(d[(int64_t)c * g.S], vb[(int64_t)c * g.S + j], acc);
+        da[(int64_t)e * g.S] = acc;
+    }
+}
+
+static int pcm_setup(const int* offsets, int E, int D, int H, int W, PcmOffsets& o, PcmGrid& g, const char* who) {
+    if (!offsets || E <= 0 || E > PCM_MAXE) {
+        set_error("%s: need 1..128 neighbour offsets", who);
+        return DRAM_EINVAL;
+    }
+    if (D <= 0 || H <= 0 || W <= 0 || (int64_t)D * H * W >= ((int64_t)1 << 31)) {
+        set_error("%s: bad grid", who);
+        return DRAM_EINVAL;
+    }
+    o.n = E;
+    for (int e = 0; e < E; ++e) {
+        for (int k = 0; k < 3; ++k)
+            if (offsets[3 * e + k] < -127 || offsets[3 * e + k] > 127) {
+                set_error("%s: offset out of range", who);
+                return DRAM_EINVAL;
+            }
+        o.dz[e] = (signed char)offsets[3 * e];
+        o.dy[e] = (signed char)offsets[3 * e + 1];
+        o.dx[e] = (signed char)offsets[3 * e + 2];
+    }
+    g.D = D; g.H = H; g.W = W; g.S = (int64_t)D * H * W;
+    return DRAM_OK;
+}
+
+}  // namespace dram
+
+using namespace dram;
+
+extern "C" int dram_pcm_attention_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
+                                      int scale_mode, float* attn, int B, int F, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(theta && phi && attn, "pcm_attention_fwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0, "pcm_attention_fwd: bad dimensions");
+    DRAM_REQUIRE((flags & ~3) == 0 && scale_mode >= 0 && scale_mode <= 2, "pcm_attention_fwd: unknown mode");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_fwd")) return rc;
+    hipLaunchKernelGGL(pcm_attn_fwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi,
+                       attn, o, g, F, flags, scale_mode);
+    return check_launch("pcm_attention_fwd");
+}
+
+extern "C" int dram_pcm_attention_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                                      const int* offsets, int E, int flags, int scale_mode, float* ds, float* dtheta,
+                                      float* dphi, int B, int F, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(theta && phi && attn && dattn && ds && dtheta && dphi, "pcm_attention_bwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0 && F <= 65535, "pcm_attention_bwd: bad dimensions");
+    DRAM_REQUIRE((flags & ~3) == 0 && scale_mode >= 0 && scale_mode <= 2, "pcm_attention_bwd: unknown mode");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pcm_attn_bwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, theta, phi, attn, dattn, ds,
+                       dtheta, o, g, F, flags, scale_mode);
+    // dphi[b,f,j] = sum_e ds[b,e,j-o_e] * theta[b,f,j-o_e]
+    hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), F, B), dim3(256), 0, st, ds, theta, dphi, o, g, F);
+    return check_launch("pcm_attention_bwd");
+}
+
+extern "C" int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets, int E, float* out, int B, int C,
+                                      int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(attn && v && out, "pcm_aggregate_fwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && C > 0 && C <= 65535, "pcm_aggregate_fwd: bad dimensions");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_aggregate_fwd")) return rc;
+    hipLaunchKernelGGL(pcm_aggregate_fwd_kernel, dim3((unsigned)cdiv64(g.S, 256), C, B), dim3(256), 0, (hipStream_t)stream, attn, v,
+                       out, o, g, C);
+    return check_launch("pcm_aggregate_fwd");
+}
+
+extern "C" int dram_pcm_aggregate_bwd(const float* attn, const float* v, const float* dout, const int* offsets, int E,
+                                      float* dattn, float* dv, int B, int C, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(attn && v && dout && dattn && dv, "pcm_aggregate_bwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && C > 0 && C <= 65535, "pcm_aggregate_bwd: bad dimensions");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_aggregate_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pcm_aggregate_dattn_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, dout, v, dattn, o, g, C);
+    // dv[b,c,j] = sum_e attn[b,e,j-o_e] * dout[b,c,j-o_e]
+    hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), C, B), dim3(256), 0, st, attn, dout, dv, o, g, C);
+    return check_launch("pcm_aggregate_bwd");
+}

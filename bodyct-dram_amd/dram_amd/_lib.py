@@ -50,8 +50,12 @@ SIGNATURES = {
     "dram_threshold_mask": (I, [P, P, F, L, P]),
     "dram_intreg_loss_ws_bytes": (Z, [I, L]),
     "dram_intreg_loss_state_floats": (I, [I]),
-    "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),
-    "dram_intreg_loss_bwd": (I, [P, P, P, P, P, P, P, P, F, P, I, L, P]),
+    "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),
+    "dram_intreg_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, F, P, P, I, L, P]),
+    "dram_pcm_attention_fwd": (I, [P, P, P, I, I, I, P, I, I, I, I, I, P]),
+    "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
+    "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
+    "dram_pcm_aggregate_bwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, P]),
 }
 
 

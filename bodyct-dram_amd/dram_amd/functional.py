@@ -5,6 +5,7 @@ stream and the autograd tape; every forward / backward computation is a call
 into the hand-written gfx950 kernels.  All tensors are fp32 NCDHW contiguous.
 There is no fallback: CPU tensors raise.
 """
+import ctypes
 import math
 
 import torch
@@ -443,18 +444,22 @@ def masked_mean(x, mask):
 
 # --------------------------------------------------------------------------- fused IntRegRefineLoss
 class IntRegRefineLossFn(Function):
-    """(reg_loss, seg_loss) of IntRegRefineLoss.__call__ (reference dram/metrics.py:360-373) for a model
-    whose two outputs are the same tensor (DC3D): one streaming pass for every sum, one for the gradient."""
+    """(reg_loss, seg_loss) of IntRegRefineLoss.__call__ (reference dram/metrics.py:360-373): one streaming
+    pass for every sum, one for the gradient.  `refined` is the model's second output (None when the
+    model returns the same tensor twice, as DC3D does)."""
 
     @staticmethod
-    def forward(ctx, dense, lobes, lesions, keep, targets, weight, smoothing):
+    def forward(ctx, dense, refined, lobes, lesions, keep, targets, weight, smoothing):
         dense = _chk(dense, "loss dense", 5)
         lobes = _chk(lobes, "loss lobes", 5)
         lesions = _chk(lesions, "loss lesions", 5)
+        if refined is not None:
+            refined = _chk(refined, "loss refined", 5)
         N = dense.shape[0]
         S = dense.numel() // N
-        if dense.shape[1] != 1 or lobes.shape != dense.shape or lesions.shape != dense.shape:
-            raise ValueError("IntRegRefineLossFn: dense / lobes / lesions must all be [N,1,D,H,W]")
+        if dense.shape[1] != 1 or lobes.shape != dense.shape or lesions.shape != dense.shape \
+                or (refined is not None and refined.shape != dense.shape):
+            raise ValueError("IntRegRefineLossFn: dense / refined / lobes / lesions must all be [N,1,D,H,W]")
         keep, targets, weight = _chk(keep, "loss keep").reshape(-1), _chk(targets, "loss targets"), _chk(weight, "loss weight")
         if keep.numel() != N or targets.numel() != 2 * N or weight.numel() != N:
             raise ValueError("IntRegRefineLossFn: keep[N], targets[N,2], weight[N] expected")
@@ -462,25 +467,115 @@ class IntRegRefineLossFn(Function):
         out = torch.empty(2, dtype=torch.float32, device=dev)
         state = torch.empty(_lib.lib.dram_intreg_loss_state_floats(N), dtype=torch.float32, device=dev)
         ws = _ws(_lib.lib.dram_intreg_loss_ws_bytes(N, S), dev)
-        call("dram_intreg_loss_fwd", _p(dense), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight),
+        call("dram_intreg_loss_fwd", _p(dense), _p(refined), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight),
              float(smoothing), _p(out), _p(state), _p(ws), ws.numel(), N, S, _stream())
-        ctx.save_for_backward(dense, lobes, lesions, keep, targets, weight, state)
+        ctx.save_for_backward(dense, lobes, lesions, keep, targets, weight, state, *(() if refined is None else (refined,)))
         ctx.smoothing = float(smoothing)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        dense, lobes, lesions, keep, targets, weight, state = ctx.saved_tensors
+        dense, lobes, lesions, keep, targets, weight, state, *rest = ctx.saved_tensors
+        refined = rest[0] if rest else None
         gout = _chk(gout, "loss grad_output", 1)
         N = dense.shape[0]
         S = dense.numel() // N
         ddense = torch.empty_like(dense)
-        call("dram_intreg_loss_bwd", _p(dense), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight), _p(state),
-             _p(gout), ctx.smoothing, _p(ddense), N, S, _stream())
-        return ddense, None, None, None, None, None, None
+        drefined = torch.empty_like(refined) if refined is not None else None
+        call("dram_intreg_loss_bwd", _p(dense), _p(refined), _p(lobes), _p(lesions), _p(keep), _p(targets), _p(weight),
+             _p(state), _p(gout), ctx.smoothing, _p(ddense), _p(drefined), N, S, _stream())
+        return ddense, drefined, None, None, None, None, None, None
 
 
-def intreg_refine_loss(dense, lobes, lesions, keep, targets, weight, smoothing=0.1):
+def intreg_refine_loss(dense, lobes, lesions, keep, targets, weight, smoothing=0.1, refined=None):
     """Returns a [2] tensor: (reg_loss, seg_loss)."""
-    return IntRegRefineLossFn.apply(dense, lobes, lesions, keep, targets, weight, smoothing)
+    if refined is dense:
+        refined = None
+    return IntRegRefineLossFn.apply(dense, refined, lobes, lesions, keep, targets, weight, smoothing)
+
+
+# --------------------------------------------------------------------------- PCM local attention
+PCM_RELU, PCM_L2NORM = 1, 2
+# merge_type -> (flags, scale_mode); reference models.py:259-331 (dot-product family)
+PCM_MERGE_MODES = {
+    "sm": (0, 0), "scaled_dot_product": (0, 1), "scaled_dot_product_relu": (PCM_RELU, 1), "smrelu": (PCM_RELU, 0),
+    "smscaled": (0, 2), "l2sm": (PCM_L2NORM, 0), "l2smrelu": (PCM_RELU | PCM_L2NORM, 0),
+}
+
+
+def _offsets_arg(offsets):
+    flat = [int(v) for o in offsets for v in o]
+    return (ctypes.c_int * len(flat))(*flat), len(flat) // 3
+
+
+class PcmAttentionFn(Function):
+    """attn[b,e,i] = softmax over node i's in-grid neighbours e of the merged theta_i . phi_(i+o_e)
+    (reference models.py: merge_func 259-331 inside compute_cross_x 365-397)."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, offsets, flags, scale_mode):
+        theta, phi = _chk(theta, "pcm theta", 5), _chk(phi, "pcm phi", 5)
+        if theta.shape != phi.shape:
+            raise ValueError(f"pcm attention: theta {tuple(theta.shape)} and phi {tuple(phi.shape)} differ")
+        B, Fd, D, H, W = theta.shape
+        arr, E = _offsets_arg(offsets)
+        attn = torch.empty((B, E, D, H, W), dtype=torch.float32, device=theta.device)
+        call("dram_pcm_attention_fwd", _p(theta), _p(phi), arr, E, flags, scale_mode, _p(attn), B, Fd, D, H, W, _stream())
+        ctx.save_for_backward(theta, phi, attn)
+        ctx.cfg = (offsets, flags, scale_mode)
+        return attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dattn):
+        theta, phi, attn = ctx.saved_tensors
+        offsets, flags, scale_mode = ctx.cfg
+        dattn = _chk(dattn, "pcm attention grad_output", 5)
+        B, Fd, D, H, W = theta.shape
+        arr, E = _offsets_arg(offsets)
+        ds = torch.empty_like(attn)
+        dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
+        call("dram_pcm_attention_bwd", _p(theta), _p(phi), _p(attn), _p(dattn), arr, E, flags, scale_mode, _p(ds),
+             _p(dtheta), _p(dphi), B, Fd, D, H, W, _stream())
+        return dtheta, dphi, None, None, None
+
+
+class PcmAggregateFn(Function):
+    """out[b,c,i] = sum_e attn[b,e,i] * v[b,c,i+o_e]  (torch.matmul(f_sm, x_g), reference models.py:394)."""
+
+    @staticmethod
+    def forward(ctx, attn, v, offsets):
+        attn, v = _chk(attn, "pcm attn", 5), _chk(v, "pcm values", 5)
+        B, C, D, H, W = v.shape
+        arr, E = _offsets_arg(offsets)
+        if tuple(attn.shape) != (B, E, D, H, W):
+            raise ValueError(f"pcm aggregate: attn {tuple(attn.shape)} does not match values {tuple(v.shape)} x {E} offsets")
+        out = torch.empty_like(v)
+        call("dram_pcm_aggregate_fwd", _p(attn), _p(v), arr, E, _p(out), B, C, D, H, W, _stream())
+        ctx.save_for_backward(attn, v)
+        ctx.offsets = offsets
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        attn, v = ctx.saved_tensors
+        dout = _chk(dout, "pcm aggregate grad_output", 5)
+        B, C, D, H, W = v.shape
+        arr, E = _offsets_arg(ctx.offsets)
+        dattn, dv = torch.empty_like(attn), torch.empty_like(v)
+        call("dram_pcm_aggregate_bwd", _p(attn), _p(v), _p(dout), arr, E, _p(dattn), _p(dv), B, C, D, H, W, _stream())
+        return dattn, dv, None
+
+
+def pcm_attention(theta, phi, offsets, merge_type):
+    if merge_type not in PCM_MERGE_MODES:
+        raise NotImplementedError(f"PCM merge_type {merge_type!r}: only the dot-product family "
+                                  f"{sorted(PCM_MERGE_MODES)} is implemented on the device")
+    flags, scale_mode = PCM_MERGE_MODES[merge_type]
+    return PcmAttentionFn.apply(theta, phi, tuple(map(tuple, offsets)), flags, scale_mode)
+
+
+def pcm_aggregate(attn, v, offsets):
+    return PcmAggregateFn.apply(attn, v, tuple(map(tuple, offsets)))

@@ -89,30 +89,33 @@ class DeviceIntRegRefineLoss:
     def __init__(self, band_width=1e-2, smoothing=0.1):
         self.band_width, self.smoothing, self.eps = band_width, smoothing, 1e-7
 
-    def __call__(self, dense, batch):
+    def __call__(self, dense, batch, refined=None):
+        """`refined`: the model's second output when it differs from `dense` (DC3DATGeneric)."""
         if dense.is_cuda:   # the product path: two fused HIP kernels (csrc/loss.hip)
             from . import functional as HF
             out = HF.intreg_refine_loss(dense, batch.lobes, batch.lesions, batch.keep, batch.targets, batch.weight,
-                                        self.smoothing)
+                                        self.smoothing, refined=refined)
             return out[0], out[1]
-        return self.reference_math(dense, batch)
+        return self.reference_math(dense, batch, refined)
 
-    def reference_math(self, dense, batch):
+    def reference_math(self, dense, batch, refined=None):
         """The same loss with torch ops (host-side specification of what csrc/loss.hip computes; used by
-        the CPU tests against the reference's golden vector)."""
-        p = torch.sigmoid(dense)
+        the CPU tests against the reference's golden vectors)."""
+        pd = torch.sigmoid(dense)
+        p = pd if refined is None or refined is dense else torch.sigmoid(refined)
         B = p.shape[0]
         lobes = batch.lobes
         inside = (lobes > 0).to(p.dtype)
-        # compute_reg_loss_with_probs (metrics.py:158-177): hinge on the lobe-mean probability
-        pred_ratio = (p * inside).view(B, -1).sum(-1) / inside.view(B, -1).sum(-1)
+        # compute_reg_loss_with_probs (metrics.py:158-177): hinge on the lobe-mean probability of dense_outs
+        pred_ratio = (pd * inside).view(B, -1).sum(-1) / inside.view(B, -1).sum(-1)
         lo, hi = batch.targets[:, 0], batch.targets[:, 1]
         K = (0.5 * (hi - lo)) ** 2
         reg = torch.clamp((pred_ratio - (hi + lo) / 2.0) ** 2 - K, min=0.0) / batch.weight
         reg_loss = reg.sum()
-        # compute_seg_loss (metrics.py:331-358): pseudo label, then BootBinCrossEntropy (metrics.py:17-51)
+        # compute_seg_loss (metrics.py:331-358): pseudo label from dense_outs, then BootBinCrossEntropy
+        # (metrics.py:17-51) on the refined probabilities
         with torch.no_grad():
-            t = ((p > 0.5) & (lobes != 0) & (batch.lesions > 0)).to(p.dtype) * batch.keep
+            t = ((pd > 0.5) & (lobes != 0) & (batch.lesions > 0)).to(p.dtype) * batch.keep
         outside = 1.0 - inside
         n_out = outside.sum()
         # outside the lobe t == 0: pt = 1 - p
@@ -184,8 +187,8 @@ class DataParallelTrainer:
         tot_reg = tot_seg = None
         for lo in range(0, n, mb):
             b = batch.micro(lo, min(n, lo + mb))
-            dense, _ = self.model(b.images, b.lobes)
-            reg, seg = self.loss_fn(dense, b)
+            dense, refined = self.model(b.images, b.lobes)
+            reg, seg = self.loss_fn(dense, b, refined=None if refined is dense else refined)
             # seg_loss is a per-micro-batch mean: weight it by its share of the rank batch
             loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * (len(b) / n)
             loss.backward()

@@ -8,16 +8,19 @@ names and state-dict keys (86 entries for the st_dram_ref config), so
 `model(images, lobes)` call (dram/metrics.py:362) and checkpoints keep working.
 All compute runs on libdram_hip.so.
 
-Out of scope of this build: `PCM` / `DC3DATGeneric`
-(DGL graph attention) are not provided.
+`models.PCM` / `models.DC3DATGeneric` (what process_pipeline.py loads) are
+provided with the reference's constructor signatures and state-dict keys; the DGL neighbour graph of
+the reference (networkx + dgl, absent here) is replaced by the equivalent voxel-grid stencil kernels
+(csrc/pcm.hip).  Parity of the attention itself is unpinned (no DGL to run the reference against): see
+oracle/dram_oracle.py.
 
 Reference citations are to /root/reference/dram/models.py.
 """
 from parts import *  # noqa: F401,F403  (the reference relies on this star import, models.py:5)
-from parts import ConvBlock5d, ConvPoolBlock5d, UpsampleConvBlock5d, checkpoint, nn, torch
+from parts import ConvBlock5d, ConvPoolBlock5d, Identity, UpsampleConvBlock5d, checkpoint, functools, nn, np, torch
 
 from dram_amd import functional as HF
-from dram_amd.modules import HipConv3d, HipUpsample
+from dram_amd.modules import HipBatchNorm3d, HipConv3d, HipReLU, HipUpsample, run_conv_stack
 
 
 class Initializer:
@@ -180,3 +183,225 @@ class DC3D(nn.Module):
         # (equal sizes: align_corners resampling is the identity -- scale (in-1)/(out-1) = 1 -- so the
         #  pass is skipped; models.py:146 always calls nn.Upsample)
         return dense_outs, dense_outs
+
+
+def _resize(x, size):
+    """F.interpolate(x, size=size, mode='trilinear', align_corners=True); the exact identity is skipped."""
+    size = tuple(int(v) for v in size)
+    if tuple(x.shape[-3:]) == size:
+        return x
+    return HF.upsample_trilinear_ac(x, size=size)
+
+
+def _channel_linear(lin, x):
+    """nn.Linear applied to the channel axis of [B,C,D,H,W] (the reference flattens to [nodes*batch, C]
+    rows, models.py:381-393) = a 1x1x1 convolution with the same weight."""
+    if not isinstance(lin, nn.Linear):
+        return x            # parts.Identity (f_dim / g_dim <= 0, models.py:169-183)
+    return HF.conv3d_k1(x, lin.weight.view(lin.out_features, lin.in_features, 1, 1, 1), lin.bias)
+
+
+class PCM(nn.Module):
+    """Local (k_size^3 neighbourhood) attention that refines a class-activation map `cam` with feature
+    affinities (models.py:150-411).  Same constructor, attributes and parameter names (theta, phi, G, r,
+    geo_theta, geo_phi) as the reference.
+
+    The reference materialises the neighbourhood as a graph (init_graph, models.py:221-258) and lets
+    DGL gather mailboxes; on a voxel grid that graph is a stencil of E offsets -- the
+    `connectivity` structuring element zoomed to k_size, minus the centre when self_loop is False,
+    clipped at the grid border (side nodes have fewer edges) -- and the forward is two kernels:
+    attention weights per (node, offset) and their weighted aggregation (csrc/pcm.hip).
+
+    Implemented merge types: the dot-product family `dram_amd.functional.PCM_MERGE_MODES`
+    (incl. the shipped 'scaled_dot_product_relu'); the others (geo / l2 / cosine / heu*) raise
+    NotImplementedError at call time, like the reference does for unknown names."""
+
+    def __init__(self, pool_size, in_ch, g_ch, f_dim, geo_f_dim, g_dim, non_local_iter, k_size,
+                 merge_type='l2', self_loop=True, connectivity=2, residual=False, p_enc_dim=32):
+        super(PCM, self).__init__()
+        self.in_ch = in_ch
+        self.g_ch = g_ch
+        self.f_dim = f_dim
+        self.g_dim = g_dim
+        self.pool_size = pool_size
+        self.merge_type = merge_type
+        self.self_loop = self_loop
+        self.non_local_iter = non_local_iter
+        self.k_size = k_size
+        self.connectivity = connectivity
+        self.residual = residual
+        self.p_enc_dim = p_enc_dim
+        self.geo_f_dim = geo_f_dim
+        if self.g_dim > 0:
+            self.G = nn.Linear(g_ch, g_dim)
+            self.r = nn.Linear(g_dim, g_ch)
+        else:
+            self.G = Identity()
+            self.r = Identity()
+            self.g_dim = g_ch
+        if f_dim > 0:
+            self.theta = nn.Linear(in_ch, f_dim)
+            self.phi = nn.Linear(in_ch, f_dim)
+        else:
+            self.theta = Identity()
+            self.phi = Identity()
+            self.f_dim = in_ch
+        if self.p_enc_dim > 0:      # parameters kept for state-dict parity; only the geo merge types read them
+            if geo_f_dim > 0:
+                self.geo_theta = nn.Linear(p_enc_dim, geo_f_dim)
+                self.geo_phi = nn.Linear(p_enc_dim, geo_f_dim)
+            else:
+                self.geo_theta = Identity()
+                self.geo_phi = Identity()
+                self.geo_f_dim = p_enc_dim
+        self.graph = None           # the reference caches its DGLGraph here; we cache the offset list
+
+    def init_graph(self, spatial_size=None, k_size=None):
+        """Neighbour offsets (dz,dy,dx) of models.py:230-232 (+ remove_self_loop, 257-258)."""
+        k = self.k_size if k_size is None else k_size
+        base = np.zeros((3, 3, 3), dtype=bool)      # ndimage.generate_binary_structure(3, connectivity)
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    base[dz + 1, dy + 1, dx + 1] = abs(dz) + abs(dy) + abs(dx) <= max(1, self.connectivity)
+        if k != 3:
+            from scipy import ndimage              # nearest-neighbour zoom exactly as the reference calls it
+            base = ndimage.zoom(base, k / 3.0, order=0)
+        off = np.asarray(np.where(base > 0)).T - np.asarray([k // 2] * 3)
+        if not self.self_loop:
+            off = off[np.any(off != 0, axis=1)]
+        return tuple(tuple(int(v) for v in o) for o in off)
+
+    def forward(self, cam, f, args=None):
+        if self.graph is None:
+            self.graph = self.init_graph(self.pool_size, self.k_size)
+        offsets = self.graph
+        theta = _channel_linear(self.theta, f)
+        phi = _channel_linear(self.phi, f)
+        attn = HF.pcm_attention(theta, phi, offsets, self.merge_type)     # f is fixed over the iterations
+        for _ in range(self.non_local_iter):
+            y = HF.pcm_aggregate(attn, _channel_linear(self.G, cam), offsets)
+            refined_cam = _channel_linear(self.r, y)
+            cam = refined_cam + cam if self.residual else refined_cam
+        return cam
+
+
+class DC3DATGeneric(nn.Module):
+    """DC3D + PCM refinement of the dense output (models.py:413-597): `forward` returns
+    (dense_outs, refined_dense_outs).  Same constructor, attribute and state-dict names as the
+    reference (ds_modules / bg / us_modules / top_layer / reshape / attention_module)."""
+
+    checkpoint_mode = "stats"       # see DC3D
+
+    def __init__(self, n_layers, in_ch_list, base_ch_list,
+                 end_ch_list, out_ch, padding_list,
+                 checkpoint_layers, dropout, at_spatial_size, at_f_dim, at_g_dim, at_p_enc_dim, at_geo_f_dim,
+                 at_g_iter, at_k_size, at_merge_type, at_self_loop, at_layers,
+                 upsample_ksize=3, upsample_sf=2, kernel_sizes=None, stacking=3,
+                 norm_method="bn", act_method='relu', pooling_method='avg', out_cls_ch=6):
+        super(DC3DATGeneric, self).__init__()
+        self.dropout = dropout
+        self.n_layers = n_layers
+        self.padding_list = padding_list
+        self.in_ch_list = in_ch_list
+        self.base_ch_list = base_ch_list
+        self.at_spatial_size = at_spatial_size
+        self.out_cls_ch = out_cls_ch
+        self.kernel_sizes = [3] * (n_layers * 2 + 1) if kernel_sizes is None else kernel_sizes
+        self.end_ch_list = end_ch_list
+        self.upsample_ksize = upsample_ksize
+        self.upsample_sf = upsample_sf
+        self.checkpoint_layers = checkpoint_layers
+        self.norm_method = norm_method
+        assert (len(end_ch_list) == len(base_ch_list) == len(in_ch_list) == len(padding_list))
+        self.out_ch = out_ch
+        self.stacking = stacking
+        self.pooling_method = pooling_method
+        self.at_f_dim = at_f_dim
+        self.at_g_dim = at_g_dim
+        self.at_g_iter = at_g_iter
+        self.at_k_size = at_k_size
+        self.at_p_enc_dim = at_p_enc_dim
+        self.at_geo_f_dim = at_geo_f_dim
+        self.at_merge_type = at_merge_type
+        self.at_self_loop = at_self_loop
+        self.at_layers = at_layers
+        conv_bias = self.norm_method is None
+
+        def level(k):
+            return ([in_ch_list[k], base_ch_list[k]], [base_ch_list[k], end_ch_list[k]],
+                    checkpoint_layers[k], self.kernel_sizes[k], padding_list[k])
+
+        down = []
+        for n in range(n_layers):
+            cin, cout, ck, ks, pad = level(n)
+            down.append(ConvPoolBlock5d(cin, cout, ck, ks, conv_bias, pad, 2, 2, 0,
+                                        norm_method=norm_method, act_method=act_method, dropout=dropout))
+        self.ds_modules = nn.ModuleList(down)
+        cin, cout, ck, ks, pad = level(n_layers)
+        self.bg = ConvBlock5d(cin, cout, ck, ks, conv_bias, pad, dropout, norm_method=norm_method, act_method=act_method)
+        up = []
+        for n in range(n_layers):
+            cin, cout, ck, ks, pad = level(n_layers + 1 + n)
+            up.append(UpsampleConvBlock5d(cin, cout, ck, self.upsample_sf, ks, conv_bias, pad,
+                                          norm_method=norm_method, act_method=act_method, dropout=dropout))
+        self.us_modules = nn.ModuleList(up)
+        self.top_layer = HipConv3d(end_ch_list[n_layers + stacking], out_ch, kernel_size=1, padding=0)
+        n_at_in_ch = at_f_dim * (len(at_layers) - 1) + 1 if -1 in at_layers else at_f_dim * len(at_layers)
+        self.reshape = nn.ModuleList([
+            nn.Sequential(HipConv3d(end_ch_list[l_id], at_f_dim, kernel_size=1, padding=0, stride=1),
+                          HipBatchNorm3d(at_f_dim), HipReLU(inplace=True))
+            for l_id in at_layers if l_id != -1])
+        self.attention_module = PCM(at_spatial_size, n_at_in_ch, out_ch, at_f_dim, at_geo_f_dim, at_g_dim, at_g_iter,
+                                    at_k_size, at_merge_type, at_self_loop, p_enc_dim=at_p_enc_dim)
+        self.dummy = torch.ones(1, requires_grad=True)
+        self.trace_path = None      # accepted and ignored: the per-scan heat-map dumps (models.py:508-539) are not built
+        self.n_pcm_layer = 0
+
+    def init(self, initializer):
+        initializer.initialize(self)
+
+    def pooling_dense_features(self, dense_outs, lungs, pooling_method='avg'):
+        return pooling_dense_features(dense_outs, lungs, pooling_method)
+
+    _run = DC3D._run
+
+    def apply_attention(self, x, lungs, dense_out, attention_features):
+        """models.py:498-506: resize the dense map to the attention grid, refine, resize back."""
+        refined = self.attention_module(_resize(dense_out, self.at_spatial_size), attention_features)
+        return _resize(refined, dense_out.shape[2:])
+
+    def forward(self, x, lungs=None):
+        L = self.n_layers
+        feats = [x] if -1 in self.at_layers else []
+        nc = 0
+
+        def tap(t):     # models.py:556,566,578: 1x1x1 conv + BN + ReLU on the *detached* feature map
+            nonlocal nc
+            feats.append(run_conv_stack([self.reshape[nc]], t.detach()))
+            nc += 1
+
+        skips = []
+        cur = x
+        for idx, ds in enumerate(self.ds_modules):
+            if self.checkpoint_layers[idx] > 0 and idx == 0:
+                feat, cur = self._run(1, ds, cur, self.dummy)
+            else:
+                feat, cur = self._run(self.checkpoint_layers[idx], ds, cur)
+            skips.append(feat)
+            if idx in self.at_layers:
+                tap(feat)
+        cur = self._run(self.checkpoint_layers[L], self.bg, cur)
+        if L in self.at_layers:
+            tap(cur)
+        for idx, (us, skip) in enumerate(zip(self.us_modules, reversed(skips))):
+            if self.stacking == idx:
+                break
+            cur = self._run(self.checkpoint_layers[L + 1 + idx], us, cur, skip)     # models.py:573 (+1, unlike DC3D)
+            if L + idx + 1 in self.at_layers:
+                tap(cur)
+        dense_outs = _resize(self.top_layer(cur), x.shape[-3:])
+        feats = [_resize(t, self.at_spatial_size) for t in feats]
+        attention_features = functools.reduce(HF.crop_concat, feats)      # torch.cat(dim=1): equal sizes, crop offset 0
+        refined_dense_outs = self.apply_attention(x, lungs, dense_outs, attention_features)
+        return dense_outs, refined_dense_outs

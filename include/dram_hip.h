@@ -200,19 +200,45 @@ int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, vo
 
 /* ---- IntRegRefineLoss, fused and device resident: dram/metrics.py:158-177 (interval hinge on
  *      the lobe-mean probability), 331-358 + 17-51 (pseudo label + BootBinCrossEntropy), 360-373 ----
- * dense, lobes, lesions: [N,1,D,H,W] (S = D*H*W); keep[N] = 0 where the CT severity score is 0 (pseudo label
- * forced to background, metrics.py:326-327), 1 otherwise; targets[N][2] = regression band (get_labels,
- * metrics.py:122-138); weight[N] = clamp(frequency, 0.2, 0.8) (metrics.py:172-174).
+ * dense, refined, lobes, lesions: [N,1,D,H,W] (S = D*H*W).  refined = the model's second output
+ * (DC3DATGeneric); NULL or == dense for DC3D, whose outputs are one tensor.  The regression term and the
+ * pseudo label use dense, the segmentation term uses refined (metrics.py:333-357, 362-364).
+ * keep[N] = 0 where the CT severity score is 0 (pseudo label forced to background, metrics.py:326-327),
+ * 1 otherwise; targets[N][2] = regression band (get_labels, metrics.py:122-138); weight[N] =
+ * clamp(frequency, 0.2, 0.8) (metrics.py:172-174).
  * out[2] = {reg_loss, seg_loss}; state (dram_intreg_loss_state_floats(N) floats) feeds the backward. */
 size_t dram_intreg_loss_ws_bytes(int N, int64_t S);
 int dram_intreg_loss_state_floats(int N);
-int dram_intreg_loss_fwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
-                         const float* targets, const float* weight, float smoothing, float* out, float* state,
-                         void* ws, size_t ws_bytes, int N, int64_t S, void* stream);
-/* ddense = d(gout[0]*reg + gout[1]*seg)/d dense; gout is a DEVICE array of 2 floats. */
-int dram_intreg_loss_bwd(const float* dense, const float* lobes, const float* lesions, const float* keep,
-                         const float* targets, const float* weight, const float* state, const float* gout,
-                         float smoothing, float* ddense, int N, int64_t S, void* stream);
+int dram_intreg_loss_fwd(const float* dense, const float* refined, const float* lobes, const float* lesions,
+                         const float* keep, const float* targets, const float* weight, float smoothing,
+                         float* out, float* state, void* ws, size_t ws_bytes, int N, int64_t S, void* stream);
+/* d(gout[0]*reg + gout[1]*seg) / d dense -> ddense and / d refined -> drefined (NULL when refined is
+ * NULL or == dense: the sum goes to ddense); gout is a DEVICE array of 2 floats. */
+int dram_intreg_loss_bwd(const float* dense, const float* refined, const float* lobes, const float* lesions,
+                         const float* keep, const float* targets, const float* weight, const float* state,
+                         const float* gout, float smoothing, float* ddense, float* drefined, int N, int64_t S,
+                         void* stream);
+
+/* ---- PCM local attention on the voxel grid: dram/models.py PCM.init_graph 221-258 (the
+ *      neighbour graph becomes E stencil offsets), merge_func 259-331 (dot-product family), compute_cross_x
+ *      365-397, forward / update_all 333-363.
+ * theta, phi: [B,F,D,H,W]; offsets: HOST array of E*3 ints (dz,dy,dx), E <= 128; node i receives from
+ * i + offset (in-grid offsets only).  attn: [B,E,D,H,W] = softmax over the node's edges of
+ * scale * normalise(act(theta_i . phi_j)); flags: DRAM_PCM_RELU | DRAM_PCM_L2NORM;
+ * scale_mode: 0 none, 1 1/sqrt(#edges of the node), 2 1/0.01. */
+#define DRAM_PCM_RELU 1
+#define DRAM_PCM_L2NORM 2
+int dram_pcm_attention_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
+                           int scale_mode, float* attn, int B, int F, int D, int H, int W, void* stream);
+/* ds: scratch [B,E,D,H,W] (receives d loss / d raw dot products); dtheta, dphi: [B,F,D,H,W]. */
+int dram_pcm_attention_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                           const int* offsets, int E, int flags, int scale_mode, float* ds, float* dtheta,
+                           float* dphi, int B, int F, int D, int H, int W, void* stream);
+/* out[b,c,i] = sum_e attn[b,e,i] * v[b,c,i+offset_e]   (torch.matmul(f_sm, x_g), models.py:394) */
+int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets, int E, float* out,
+                           int B, int C, int D, int H, int W, void* stream);
+int dram_pcm_aggregate_bwd(const float* attn, const float* v, const float* dout, const int* offsets, int E,
+                           float* dattn, float* dv, int B, int C, int D, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

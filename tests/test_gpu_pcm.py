@@ -1,0 +1,167 @@
+"""GPU parity of SURVEY row N2: the PCM local-attention kernels (csrc/pcm.hip) and DC3DATGeneric.
+
+PCM itself is PARITY UNPINNED (the reference needs DGL, absent): the kernels are compared with the
+oracle's restatement in fp64 (itself cross-checked against a literal node-by-node restatement in
+tests/test_oracle_golden.py).  Everything of DC3DATGeneric around the PCM call is compared with the
+reference's own outputs (tests/golden/dc3dat_slim.npz, generated with a pass-through attention)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dram_oracle as O
+from oracle.make_golden import SLIM_ATT
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(got, ref):
+    ref = torch.as_tensor(ref).double()
+    got = torch.as_tensor(got).detach().cpu().double()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("merge", O.PCM_DOT_MERGES)
+@pytest.mark.parametrize("shape,self_loop,iters,residual,conn", [
+    ((5, 4, 7), False, 1, False, 2), ((1, 2, 3), True, 1, False, 2), ((8, 8, 8), False, 2, True, 2), ((6, 5, 4), True, 1, False, 1),
+    ((4, 6, 5), False, 1, False, 3)])
+def test_pcm_module_matches_oracle(merge, shape, self_loop, iters, residual, conn):
+    import models
+    torch.manual_seed(3)
+    B, C, Fd, G, Gd = 2, 9, 4, 2, 3
+    m = models.PCM(shape, C, G, Fd, 0, Gd, iters, 3, merge_type=merge, self_loop=self_loop, connectivity=conn,
+                   residual=residual, p_enc_dim=0)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(3.0)         # spread the logits so the softmax is far from uniform
+    g = torch.Generator().manual_seed(4)
+    cam = torch.randn((B, G) + shape, generator=g)
+    f = torch.randn((B, C) + shape, generator=g)
+    if merge == "smscaled":     # logits / 0.01: keep the softmax out of saturation (gradients would all be ~1e-12)
+        f = f * 0.03
+    gout = torch.randn((B, G) + shape, generator=g)
+    # oracle, fp64
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    cam64, f64 = cam.double().requires_grad_(True), f.double().requires_grad_(True)
+    ref = _oracle_pcm(p64, cam64, f64, conn, self_loop, merge, iters, residual)
+    (ref * gout.double()).sum().backward()
+    # device
+    m = m.cuda()
+    camg, fg = cam.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
+    out = m(camg, fg)
+    (out * gout.cuda()).sum().backward()
+    assert rel(out, ref) <= TOL
+    assert rel(camg.grad, cam64.grad) <= TOL
+    assert rel(fg.grad, f64.grad) <= TOL
+    # phi.bias shifts every logit of a node equally: its exact gradient is 0 for the plain softmax merges, so
+    # parameter gradients are compared on the scale of the largest one
+    scale = max(v.grad.abs().max().item() for v in p64.values())
+    for k, p in m.named_parameters():
+        err = (p.grad.detach().cpu().double() - p64[k].grad).abs().max().item()
+        assert err <= TOL * max(scale, 1e-30), (k, err, scale)
+
+
+def _oracle_pcm(p, cam, f, conn, self_loop, merge, iters, residual):
+    return O.pcm_forward(p, cam, f, 3, conn, self_loop, merge, iters, residual)
+
+
+def test_pcm_offsets_match_oracle():
+    import models
+    for conn in (1, 2, 3):
+        for sl in (False, True):
+            for k in (3, 5):
+                m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, k, merge_type="sm", self_loop=sl, connectivity=conn, p_enc_dim=0)
+                assert sorted(m.init_graph()) == sorted(tuple(int(v) for v in o) for o in O.pcm_offsets(k, conn, sl))
+    with pytest.raises(NotImplementedError):
+        m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, 3, merge_type="cosine", p_enc_dim=0).cuda()
+        m(torch.zeros(1, 1, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
+
+
+def _load_att(golden_dir):
+    import models
+    z = np.load(os.path.join(golden_dir, "dc3dat_slim.npz"))
+    tag = "slim_att"
+    sd = {k[len(tag + "/sd/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/sd/")}
+    m = models.DC3DATGeneric(**SLIM_ATT)
+    m.load_state_dict(sd)           # strict: the reference's 108 keys, names and shapes
+    return z, tag, sd, m
+
+
+def test_dc3dat_wiring_matches_reference_golden(golden_dir):
+    z, tag, sd, m = _load_att(golden_dir)
+
+    class PassThrough(torch.nn.Module):     # what oracle/make_golden.py:gen_att put in the reference
+        def forward(self, cam, feats, args=None):
+            self.seen = feats
+            return cam
+    m.attention_module = PassThrough()
+    m = m.cuda().train()
+    x = torch.from_numpy(z[tag + "/x"]).cuda()
+    d0, d1 = m(x, None)
+    feats = m.attention_module.seen
+    assert rel(d0, z[tag + "/dense"]) <= TOL and rel(d1, z[tag + "/refined"]) <= TOL and rel(feats, z[tag + "/feats"]) <= TOL
+    t = lambda k: torch.from_numpy(z[tag + k]).cuda()
+    ((d0 * t("/gout0")).sum() + (d1 * t("/gout1")).sum() + (feats * t("/goutf")).sum()).backward()
+    grads = {k[len(tag + "/grad/"):]: z[k] for k in z.files if k.startswith(tag + "/grad/")}
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(grads)
+    gmax = max(float(np.abs(v).max()) for v in grads.values())
+    for k in grads:
+        if k.startswith("reshape.") and k.endswith(".0.bias"):
+            # a conv bias in front of BatchNorm: the exact gradient is 0, both sides hold rounding noise
+            assert float(got[k].abs().max()) <= 1e-5 * gmax and float(np.abs(grads[k]).max()) <= 1e-5 * gmax, k
+        elif k.startswith(("reshape.", "top_layer", "us_modules.2")):
+            assert rel(got[k], grads[k]) <= 2e-3, k      # BatchNorm network in fp32: see test_gpu_parity.check_grads
+    for k in z.files:
+        if k.startswith(tag + "/sd_after/") and "running" in k:
+            name = k[len(tag + "/sd_after/"):]
+            assert rel(m.state_dict()[name], z[k]) <= TOL, name
+
+
+def test_dc3dat_with_attention_matches_oracle(golden_dir):
+    z, tag, sd, m = _load_att(golden_dir)
+    params, buffers = O.split_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in sd.items()})
+    for p in params.values():
+        p.requires_grad_(True)
+    x = torch.from_numpy(z[tag + "/x"])
+    dense_r, refined_r, _ = O.dc3dat_forward(SLIM_ATT, params, buffers, x.double(), training=True, attention=True)
+    g1 = torch.from_numpy(z[tag + "/gout1"])
+    (refined_r * g1.double()).sum().backward()
+    m = m.cuda().train()
+    d0, d1 = m(x.cuda(), None)
+    assert d0 is not d1
+    (d1 * g1.cuda()).sum().backward()
+    assert rel(d0, dense_r) <= TOL and rel(d1, refined_r) <= TOL
+    for k in ("attention_module.theta.weight", "attention_module.phi.weight", "attention_module.G.weight",
+              "attention_module.r.weight", "attention_module.r.bias", "reshape.0.0.weight", "reshape.1.1.bias",
+              "top_layer.weight"):
+        got = dict(m.named_parameters())[k].grad
+        assert rel(got, params[k].grad) <= 5e-3, k
+
+
+def test_fused_loss_two_outputs_matches_reference_golden(golden_dir):
+    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    z = np.load(os.path.join(golden_dir, "loss2.npz"))
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    batch = Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), {k: 1.0 / 6 for k in range(6)}, band_width=1e-2)
+    dense, refined = t("dense").requires_grad_(True), t("refined").requires_grad_(True)
+    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dense, batch, refined=refined)
+    assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
+    assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
+    (2.0 * reg + 1.0 * seg).backward()
+    assert rel(dense.grad, z["gdense"]) <= TOL and rel(refined.grad, z["grefined"]) <= TOL
+
+
+def test_trainer_step_dc3dat(golden_dir):
+    """One DataParallelTrainer step drives DC3DATGeneric end to end (two outputs through the fused loss)."""
+    from dram_amd.train_step import DataParallelTrainer, synthetic_batch
+    z, tag, sd, m = _load_att(golden_dir)
+    m = m.cuda().train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    tr = DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=1e-3))
+    reg, seg = tr.step(synthetic_batch(4, 16, 100, torch.device("cuda")), micro_batch=2)
+    assert torch.isfinite(reg) and torch.isfinite(seg)
+    moved = [k for k, v in m.named_parameters() if not torch.equal(v, before[k])]
+    assert any(k.startswith("attention_module.") for k in moved) and any(k.startswith("ds_modules.0") for k in moved)

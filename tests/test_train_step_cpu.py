@@ -66,3 +66,18 @@ def test_gradient_allreduce_two_ranks_gloo():
         out = mgr.dict()
         mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def test_device_loss_two_outputs_matches_reference_golden(golden_dir):
+    """DC3DATGeneric case: regression term + pseudo label from dense_outs, segmentation term on refined."""
+    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    z = np.load(os.path.join(golden_dir, "loss2.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    batch = Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), {k: 1.0 / 6 for k in range(6)}, band_width=1e-2)
+    dense, refined = t("dense").clone().requires_grad_(True), t("refined").clone().requires_grad_(True)
+    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dense, batch, refined=refined)
+    assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
+    assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
+    (2.0 * reg + 1.0 * seg).backward()
+    assert np.abs(dense.grad.numpy() - z["gdense"]).max() <= 1e-4 * np.abs(z["gdense"]).max()
+    assert np.abs(refined.grad.numpy() - z["grefined"]).max() <= 1e-4 * np.abs(z["grefined"]).max()
