@@ -95,7 +95,7 @@ class LobeInference:
              float(self.window[0]), float(self.window[1]), st)
         was_training = self.model.training
         self.model.eval()
-        dense, _ = self.model(x, None)                                       # one batch of L lobe chunks
+        _, dense = self.model(x, None)       # one batch of L lobe chunks; the 2nd output is used (job_runner.py:764)
         self.model.train(was_training)
         call("dram_lobe_paste", dense.contiguous().data_ptr(), lobe.data_ptr(), htp.data_ptr(), carr, L, D, H, W, R, st)
         hist = torch.empty(256, dtype=torch.int64, device=dev)

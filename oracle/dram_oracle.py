@@ -464,10 +464,12 @@ def binary_cam(cam_np, scaler=1.0, from_span=(0, 1)):
 
 
 def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", resample=80,
-                  window=(-1000.0, -300.0), border=5.0):
+                  window=(-1000.0, -300.0), border=5.0, forward=None):
     """evaluate_scan (job_runner.py:729-770) + the thresholding of LesionSegTest.run
     (job_runner.py:1003-1005), one lobe at a time like the reference.  The crop -> resample^3 step
-    uses trilinear/align_corners (this build's definition, see dram_amd/inference.py)."""
+    uses trilinear/align_corners (this build's definition, see dram_amd/inference.py).
+    `forward(t) -> logits` replaces the DC3D forward (e.g. the refined output of dc3dat_forward: the
+    reference takes the model's *second* output, job_runner.py:764)."""
     htp = np.zeros(scan.shape, dtype=np.float32)
     with torch.no_grad():
         for label in np.unique(lobe)[1:]:
@@ -480,7 +482,8 @@ def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", r
             img = windowing(scan_chunk, from_span=window, to_span=(0.0, 1.0)).astype(np.float32)
             t = torch.from_numpy(img)[None, None]
             t = upsample_trilinear_ac(t, size=(resample,) * 3)
-            dense = dc3d_forward(cfg, params, buffers, t, training=False, norm_method=norm_method)
+            dense = forward(t) if forward is not None else \
+                dc3d_forward(cfg, params, buffers, t, training=False, norm_method=norm_method)
             probs = torch.sigmoid(dense)
             probs = upsample_trilinear_ac(probs, size=tuple(crop_size))[0, 0].numpy()
             view = htp[sl]

@@ -63,3 +63,25 @@ def test_inference_kernels_edge_cases():
     params, buffers = O.split_state_dict({k: v.cpu().clone() for k, v in model.state_dict().items()})
     htp_ref, mask_ref, th_ref, _ = O.evaluate_scan(SLIM, params, buffers, scan, lobe, (1.0, 1.0, 1.0), resample=16)
     assert np.abs(res["htp"].cpu().numpy() - htp_ref).max() <= 1e-4
+
+
+def test_lobe_inference_with_attention_model(golden_dir):
+    """The same pipeline with DC3DATGeneric (what process_pipeline.py loads): the refined (second) output
+    is what gets pasted (job_runner.py:764)."""
+    import os
+    import models
+    from dram_amd.inference import LobeInference, dice, synthetic_ct
+    from oracle.make_golden import SLIM_ATT
+    z = np.load(os.path.join(golden_dir, "dc3dat_slim.npz"))
+    sd = {k[len("slim_att/sd/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("slim_att/sd/")}
+    m = models.DC3DATGeneric(**SLIM_ATT)
+    m.load_state_dict(sd)
+    params, buffers = O.split_state_dict(sd)
+    scan, lobe, spacing = synthetic_ct((41, 57, 66), (2.5, 1.0, 1.0), seed=7, n_lesions=8)
+    res = LobeInference(m.cuda().eval(), resample_size=24).run(scan, lobe, spacing)
+    fwd = lambda t: O.dc3dat_forward(SLIM_ATT, params, buffers, t, training=False, attention=True)[1]
+    htp_ref, mask_ref, th_ref, ratio_ref = O.evaluate_scan(SLIM_ATT, params, buffers, scan, lobe, spacing, resample=24,
+                                                           forward=fwd)
+    htp = res["htp"].cpu().numpy()
+    assert np.abs(htp - htp_ref).max() <= 1e-4
+    assert dice(res["mask"].cpu().numpy() > 0, mask_ref) >= 0.999
