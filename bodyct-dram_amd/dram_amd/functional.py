@@ -55,20 +55,26 @@ def _timed_call(key, flops, nbytes, name, *args):
     TIMER.records.append((key, flops, nbytes, e0, e1))
 
 
-def conv_fwd_kernel_name(W, Cout):
+def _pick_box(dhw, boxes):
+    """csrc/conv3d_k3.hip pick_box: the box that pads the volume least, ties to the first listed."""
+    D, H, W = dhw
+    vol = lambda b: -(-W // b[0]) * b[0] * (-(-H // b[1]) * b[1]) * (-(-D // b[2]) * b[2])
+    return min(boxes, key=vol)
+
+
+def conv_fwd_kernel_name(dhw, Cout):
     """Name of the conv3d_k3_fwd_kernel instantiation the library picks (csrc/conv3d_k3.hip
     conv_fwd_dispatch / launch_fwd), as rocprofv3 prints it."""
-    box = "32, 4, 2" if W >= 24 else ("16, 4, 4" if W >= 12 else "8, 8, 4")
-    return f"conv3d_k3_fwd_kernel<{box}, {1 if Cout <= 32 else 2}>"
+    box = _pick_box(dhw, [(32, 4, 2), (16, 4, 4), (8, 8, 4)])
+    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {1 if Cout <= 32 else 2}>"
 
 
-def conv_wgrad_kernel_name(W, Cout, Cin=None):
+def conv_wgrad_kernel_name(dhw, Cout, Cin=None):
     if Cin == 1:
         return "conv3d_k3_wgrad_c1_kernel"
-    bx = 32 if W >= 24 else (16 if W >= 12 else 8)
-    box = {32: "32, 2, 1", 16: "16, 2, 2", 8: "8, 4, 2"}[bx]
-    kind = "wgrad_vec" if W % bx == 0 else "wgrad"       # 16-byte staging needs full boxes along x
-    return f"conv3d_k3_{kind}_kernel<{box}, {'8, 1' if Cout > 64 else '4, 2'}>"
+    box = _pick_box(dhw, [(16, 2, 2), (32, 2, 1), (8, 4, 2)])
+    kind = "wgrad_vec" if dhw[2] % box[0] == 0 else "wgrad"       # 16-byte staging needs full boxes along x
+    return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {'8, 1' if Cout > 64 else '4, 2'}>"
 
 
 def _p(t):
@@ -134,7 +140,7 @@ class Conv3dK3Fn(Function):
         wt = _pack(w, 0)
         y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x1.device)
         vox = N * D * H * W
-        _timed_call(conv_fwd_kernel_name(W, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+        _timed_call(conv_fwd_kernel_name((D, H, W), Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                     "dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
                     _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
         ctx.save_for_backward(x1, x2, w)
@@ -161,7 +167,7 @@ class Conv3dK3Fn(Function):
                 full = (D2, H2, W2) == (D, H, W)
                 dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
             vox = N * D * H * W
-            _timed_call(conv_fwd_kernel_name(W, Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_fwd_kernel_name((D, H, W), Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                         _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
             if not need1:
@@ -173,7 +179,7 @@ class Conv3dK3Fn(Function):
             nbytes = _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)
             ws = _ws(nbytes, dy.device)
             vox = N * D * H * W
-            _timed_call(conv_wgrad_kernel_name(W, Co, Ci if x2 is None else None), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_wgrad_kernel_name((D, H, W), Co, Ci if x2 is None else None), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
                         _p(ws), ws.numel(), N, Co, D, H, W, st)
         if ctx.has_bias and ctx.needs_input_grad[3]:
