@@ -52,6 +52,11 @@ SIGNATURES = {
     "dram_intreg_loss_state_floats": (I, [I]),
     "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),
     "dram_intreg_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, F, P, P, I, L, P]),
+    "dram_prelu_fwd": (I, [P, P, P, I, I, I, L, P]),
+    "dram_prelu_bwd_ws_bytes": (Z, [I, I, L]),
+    "dram_prelu_bwd": (I, [P, P, P, P, P, P, Z, I, I, I, L, P]),
+    "dram_global_max_fwd": (I, [P, P, P, I, L, P]),
+    "dram_global_max_bwd": (I, [P, P, P, I, L, P]),
     "dram_pcm_attention_fwd": (I, [P, P, P, I, I, I, P, I, I, I, I, I, P]),
     "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),

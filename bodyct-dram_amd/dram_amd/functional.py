@@ -316,6 +316,70 @@ def relu(x):
 
 
 # --------------------------------------------------------------------------- max pool 2x2x2
+class PReLUFn(Function):
+    """nn.PReLU (act_wrapper "prelu", reference parts.py:51-52)."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        x, a = _chk(x, "prelu input"), _chk(a, "prelu weight", 1)
+        if x.dim() < 2:
+            raise ValueError("prelu: expected (N, C, *spatial)")
+        N, C = x.shape[0], x.shape[1]
+        if a.numel() not in (1, C):
+            raise ValueError(f"prelu: {a.numel()} parameters for {C} channels")
+        y = torch.empty_like(x)
+        call("dram_prelu_fwd", _p(x), _p(a), _p(y), N, C, a.numel(), x.numel() // (N * C), _stream())
+        ctx.save_for_backward(x, a)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        dy = _chk(dy, "prelu grad_output")
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        da = torch.empty_like(a)
+        ws = _ws(_lib.lib.dram_prelu_bwd_ws_bytes(N, C, S), x.device)
+        call("dram_prelu_bwd", _p(dy), _p(x), _p(a), _p(dx), _p(da), _p(ws), ws.numel(), N, C, a.numel(), S, _stream())
+        return dx, da
+
+
+def prelu(x, a):
+    return PReLUFn.apply(x, a)
+
+
+class GlobalMaxFn(Function):
+    """F.adaptive_max_pool3d(x, 1).view(B, C) (reference models.py:41-42)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "global max input")
+        B, C = x.shape[0], x.shape[1]
+        S = x.numel() // (B * C)
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, C), dtype=torch.int64, device=x.device)
+        call("dram_global_max_fwd", _p(x), _p(out), _p(idx), B * C, S, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dout = _chk(dout, "global max grad_output")
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        B, C = ctx.shape[0], ctx.shape[1]
+        call("dram_global_max_bwd", _p(dout), _p(idx), _p(dx), B * C, dx.numel() // (B * C), _stream())
+        return dx
+
+
+def global_max(x):
+    return GlobalMaxFn.apply(x)
+
+
 class MaxPool2Fn(Function):
     """nn.MaxPool3d(2, 2, 0) (reference parts.py:191)."""
 

@@ -84,6 +84,13 @@ class HipReLU(nn.ReLU):
         return HF.relu(x)
 
 
+class HipPReLU(nn.PReLU):
+    """nn.PReLU(num_parameters, init) (act_wrapper "prelu", parts.py:51-52)."""
+
+    def forward(self, x):
+        return HF.prelu(x, self.weight)
+
+
 class HipMaxPool3d(nn.MaxPool3d):
     """nn.MaxPool3d(2, 2, 0) (parts.py:191)."""
 

@@ -62,7 +62,7 @@ def pooling_dense_features(dense_outs, lungs, pooling_method='avg'):
         ones = torch.ones((B, 1) + tuple(dense_outs.shape[2:]), dtype=dense_outs.dtype, device=dense_outs.device)
         return HF.masked_mean(dense_outs, ones).view(B, C)
     if pooling_method == 'global_max':
-        raise NotImplementedError("pooling_method='global_max' is not implemented on the HIP path")
+        return HF.global_max(dense_outs)
     lungs_expand = lungs.expand(B, 1, *dense_outs.shape[2:]) if lungs.shape[1] == 1 else None
     if lungs_expand is None:
         raise ValueError("pooling_dense_features: lungs must be a [B,1,D,H,W] mask")

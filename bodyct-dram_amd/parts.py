@@ -19,7 +19,7 @@ import torch.nn.functional as F  # noqa: F401
 from torch.utils.checkpoint import checkpoint, checkpoint_sequential  # noqa: F401
 
 from dram_amd import functional as HF
-from dram_amd.modules import (HipBatchNorm3d, HipConv3d, HipGroupNorm, HipMaxPool3d, HipReLU, HipSyncBatchNorm,
+from dram_amd.modules import (HipBatchNorm3d, HipConv3d, HipGroupNorm, HipMaxPool3d, HipPReLU, HipReLU, HipSyncBatchNorm,
                               HipUpsample, run_conv_stack)
 
 
@@ -66,9 +66,7 @@ def act_wrapper(act_method, num_parameters=1, init=0.25):
     if act_method == "relu":
         return HipReLU(inplace=True)
     if act_method == "prelu":
-        # nn.PReLU has no HIP kernel in this build; the shipped configs never select it
-        # (ConvBlock5d / UpsampleConvBlock5d cannot even receive it: their kwarg is `act_methpd`).
-        raise NotImplementedError("act_method='prelu' is not implemented on the HIP path")
+        return HipPReLU(num_parameters, init)
     raise NotImplementedError
 
 

@@ -198,6 +198,18 @@ int dram_lung_hist256(const float* htp, const uint8_t* lobe, unsigned long long*
 /* mask[v] = htp[v] > th. */
 int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, void* stream);
 
+/* ---- nn.PReLU (act_wrapper "prelu", dram/parts.py:51-52): y = x > 0 ? x : a*x, a[nparam], nparam in {1, C};
+ *      x: [N,C,S].  bwd: dx (may be NULL), da[nparam] = sum dy*x over x <= 0 (deterministic) ---- */
+int dram_prelu_fwd(const float* x, const float* a, float* y, int N, int C, int nparam, int64_t S, void* stream);
+size_t dram_prelu_bwd_ws_bytes(int N, int C, int64_t S);
+int dram_prelu_bwd(const float* dy, const float* x, const float* a, float* dx, float* da, void* ws,
+                   size_t ws_bytes, int N, int C, int nparam, int64_t S, void* stream);
+
+/* ---- F.adaptive_max_pool3d(x, 1) (pooling_dense_features 'global_max', dram/models.py:41-42): per (n,c) row
+ *      the maximum and the index of its first occurrence; bwd routes dout to that element ---- */
+int dram_global_max_fwd(const float* x, float* out, int64_t* idx, int NC, int64_t S, void* stream);
+int dram_global_max_bwd(const float* dout, const int64_t* idx, float* dx, int NC, int64_t S, void* stream);
+
 /* ---- IntRegRefineLoss, fused and device resident: dram/metrics.py:158-177 (interval hinge on
  *      the lobe-mean probability), 331-358 + 17-51 (pseudo label + BootBinCrossEntropy), 360-373 ----
  * dense, refined, lobes, lesions: [N,1,D,H,W] (S = D*H*W).  refined = the model's second output

@@ -241,6 +241,34 @@ def gen_loss():
     _save("loss", **arrs)
 
 
+def gen_misc(parts, models):
+    """The less-travelled factory branches: act_wrapper "prelu" (parts.py:51-52) inside a ConvPoolBlock5d,
+    a per-channel nn.PReLU on its own, and pooling_dense_features 'global_avg' / 'global_max' / default
+    (models.py:37-49) with ties in the maximum."""
+    arrs = {}
+    g = torch.Generator().manual_seed(4321)
+    torch.manual_seed(21)
+    blk = parts.ConvPoolBlock5d([3, 4], [4, 6], 0, (3, 3), False, (1, 1), 2, 2, 0, dropout=0.0, norm_method="bn",
+                                act_method="prelu")
+    assert any(isinstance(m, torch.nn.PReLU) for m in blk.modules())
+    x = torch.randn(2, 3, 7, 9, 11, generator=g)
+    _block_case("convpool_prelu", blk, [x], ["y", "pooled"], arrs, seed=9)
+    act = parts.act_wrapper("prelu", 5, 0.1)
+    act.weight.data = torch.rand(5, generator=g) - 0.3
+    x = torch.randn(3, 5, 4, 6, 7, generator=g)
+    _block_case("prelu_c", act, [x], ["y"], arrs, seed=10)
+    dense = torch.randn(2, 3, 5, 6, 7, generator=g).round()        # rounded: repeated maxima
+    lungs = (torch.rand(2, 1, 5, 6, 7, generator=g) > 0.5).float()
+    for method in ("global_avg", "global_max", "avg"):
+        d = dense.clone().requires_grad_(True)
+        out = models.pooling_dense_features(d, lungs, method)
+        go = torch.randn(out.shape, generator=g)
+        (out * go).sum().backward()
+        arrs[f"pool/{method}/out"], arrs[f"pool/{method}/gout"], arrs[f"pool/{method}/gin"] = _np(out), _np(go), _np(d.grad)
+    arrs["pool/dense"], arrs["pool/lungs"] = _np(dense), _np(lungs)
+    _save("misc", **arrs)
+
+
 SLIM_ATT = dict(SLIM, at_spatial_size=(6, 5, 7), at_f_dim=4, at_g_dim=3, at_g_iter=1, at_k_size=3,
                 at_merge_type="scaled_dot_product_relu", at_self_loop=False, at_layers=[-1, 0, 1],
                 at_p_enc_dim=0, at_geo_f_dim=0)
@@ -327,6 +355,8 @@ if __name__ == "__main__":
         gen_models(models)
     if not only or "att" in only:
         gen_att(models)
+    if not only or "misc" in only:
+        gen_misc(parts, models)
     if not only or "loss" in only:
         gen_loss()
     if not only or "loss2" in only:
