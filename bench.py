@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
+                    "gloo only to rehearse the multi-rank path with several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -120,8 +122,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:                                  # rehearsal: ranks may share a GPU
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
