@@ -451,24 +451,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_kernel(WgradArgs a) {
         const float* bp = lx + (wci * 16 + i) * PB + k;
         constexpr int NS = VOX / 4;
         float av[2], bv[2][27];
+        // two operand sets live; one operand read of k-step s beside each MFMA of k-step s-1 (see the vec kernel)
 #pragma unroll
         for (int s = 0; s <= NS; ++s) {
-            if (s < NS) {
-                const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
-                av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
-                const float* bq = bp + (vz * HY + vy) * HX + 4 * x4;
+            const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
+            const float* bq = bp + (vz * HY + vy) * HX + 4 * x4;
+            if (s < NS) av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
 #pragma unroll
-                for (int tap = 0; tap < 27; ++tap) {
-                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                    bv[s & 1][tap] = bq[(dz * HY + dy) * HX + dx];
-                }
-            }
-            if (s > 0) {
-#pragma unroll
-                for (int tap = 0; tap < 27; ++tap)
+            for (int tap = 0; tap < 27; ++tap) {
+                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                if (s < NS) bv[s & 1][tap] = bq[(dz * HY + dy) * HX + dx];
+                if (s > 0)
                     acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(s - 1) & 1], bv[(s - 1) & 1][tap], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep exactly two operand sets live: reads(s) + MFMAs(s-1) per region
         }
     };
 
@@ -659,24 +655,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a
         const float* bp = lx + (wci * 16 + i) * PB + k + 3;
         constexpr int NS = VOX / 4;
         float av[2], bv[2][27];
+        // one operand read of k-step s beside each MFMA of k-step s-1: the 28 LDS reads of a step are spread over
+        // its 27 MFMA slots instead of being issued as one burst that the 4-bit lgkmcnt counter throttles
 #pragma unroll
         for (int s = 0; s <= NS; ++s) {
-            if (s < NS) {
-                const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
-                av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
-                const float* bq = bp + (vz * HY + vy) * HXP + 4 * x4;
+            const int x4 = s % (BX / 4), vy = (s / (BX / 4)) % BY, vz = s / ((BX / 4) * BY);
+            const float* bq = bp + (vz * HY + vy) * HXP + 4 * x4;
+            if (s < NS) av[s & 1] = ap[(vz * BY + vy) * BX + 4 * x4];
 #pragma unroll
-                for (int tap = 0; tap < 27; ++tap) {
-                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                    bv[s & 1][tap] = bq[(dz * HY + dy) * HXP + dx];
-                }
-            }
-            if (s > 0) {
-#pragma unroll
-                for (int tap = 0; tap < 27; ++tap)
+            for (int tap = 0; tap < 27; ++tap) {
+                const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                if (s < NS) bv[s & 1][tap] = bq[(dz * HY + dy) * HXP + dx];
+                if (s > 0)
                     acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(s - 1) & 1], bv[(s - 1) & 1][tap], acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
