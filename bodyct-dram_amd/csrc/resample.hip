@@ -183,6 +183,38 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
     }
 }
 
+// Two-stage adjoint, stage 1: reduce along z only.  tmp[plane][zi][yo][xo] = sum_kz wz * dy[plane][tz.lo+kz][yo][xo],
+// four x at a time (rows are contiguous in xo: coalesced 16-byte loads, no index arithmetic per tap).  Stage 2 is
+// trilinear_bwd_kernel itself on tmp with an identity z axis.  A coarse output then costs ~4 float4 + 16 scalar
+// loads instead of 64 scalar ones, and the strided (every second x) gathers run over a tensor half the size.
+__global__ __launch_bounds__(256) void trilinear_bwd_z_kernel(const float* __restrict__ dy, float* __restrict__ tmp,
+                                                              Axis az, int Ho, int Wo, int planes) {
+    const int W4 = Wo >> 2;
+    const int per_plane4 = az.in * Ho * W4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_plane4) return;
+    const int zi = e / (Ho * W4);
+    const int rem = e - zi * (Ho * W4);           // (yo, xo4) linear = offset/4 inside a z slab
+    const Taps tz = axis_taps(az, zi);
+    const int64_t slab = (int64_t)Ho * Wo;         // floats per z slab of dy / tmp
+    const int64_t So = (int64_t)az.out * slab, St = (int64_t)az.in * slab;
+    const int p0 = blockIdx.y * TRI_CPT;
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        const float* p = dy + (int64_t)plane * So + (int64_t)tz.lo * slab + 4 * (int64_t)rem;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kz = 0; kz < MAXT; ++kz)
+            if (kz < tz.n) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)kz * slab);
+                const float w = tz.w[kz];
+                acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            }
+        *reinterpret_cast<float4*>(tmp + (int64_t)plane * St + (int64_t)zi * slab + 4 * (int64_t)rem) = acc;
+    }
+}
+
 // general fallback (any magnification): plane per blockIdx.y, weights recomputed inside the loops
 __global__ __launch_bounds__(256) void trilinear_bwd_general_kernel(const float* __restrict__ dy,
                                                                     float* __restrict__ dx, Axis az, Axis ay, Axis ax) {
@@ -308,6 +340,43 @@ extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, i
     hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
                        make_axis(H, Ho), make_axis(W, Wo), N * C);
     return check_launch("upsample_trilinear_ac_fwd");
+}
+
+// Two-stage backward (z first, then y/x) through a caller-provided workspace; planes are processed in groups
+// that fit the workspace.  Falls back to the single-stage kernel when the shape does not qualify.
+static bool tri_two_stage_ok(const float* dy, int D, int H, int W, int Do, int Ho, int Wo) {
+    return Do > D && (Wo % 4) == 0 && (((uintptr_t)dy) & 15) == 0 && max_taps_host(D, Do) <= MAXT &&
+           max_taps_host(H, Ho) <= MAXT && max_taps_host(W, Wo) <= MAXT && (int64_t)D * Ho * Wo < 0x7fffffffLL;
+}
+
+extern "C" size_t dram_upsample_trilinear_ac_bwd_ws_bytes(int N, int C, int D, int H, int W, int Do, int Ho, int Wo) {
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= D || (Wo % 4) != 0) return 0;
+    return (size_t)N * C * D * Ho * Wo * sizeof(float);
+}
+
+extern "C" int dram_upsample_trilinear_ac_bwd_ws(const float* dy, float* dx, void* ws, size_t ws_bytes, int N, int C,
+                                                 int D, int H, int W, int Do, int Ho, int Wo, void* stream) {
+    DRAM_REQUIRE(dy && dx, "upsample_trilinear_ac_bwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_bwd: bad sizes");
+    const size_t per_plane = (size_t)D * Ho * Wo * sizeof(float);
+    int64_t group = ws ? (int64_t)(ws_bytes / per_plane) : 0;
+    group -= group % TRI_CPT;
+    if (group < TRI_CPT || (((uintptr_t)ws) & 15) != 0 || !tri_two_stage_ok(dy, D, H, W, Do, Ho, Wo))
+        return dram_upsample_trilinear_ac_bwd(dy, dx, N, C, D, H, W, Do, Ho, Wo, stream);
+    int rc = check_planes("upsample_trilinear_ac_bwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t planes = (int64_t)N * C;
+    const Axis az = make_axis(D, Do), ay = make_axis(H, Ho), ax = make_axis(W, Wo), idz = make_axis(D, D);
+    const int64_t So = (int64_t)Do * Ho * Wo, S = (int64_t)D * H * W;
+    for (int64_t p0 = 0; p0 < planes; p0 += group) {
+        const int g = (int)((planes - p0) < group ? (planes - p0) : group);
+        hipLaunchKernelGGL(trilinear_bwd_z_kernel, dim3(cdiv(D * Ho * (Wo / 4), 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
+                           dy + p0 * So, (float*)ws, az, Ho, Wo, g);
+        hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(cdiv(D * H * W, 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
+                           (const float*)ws, dx + p0 * S, idz, ay, ax, g);
+    }
+    return check_launch("upsample_trilinear_ac_bwd(two-stage)");
 }
 
 extern "C" int dram_upsample_trilinear_ac_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, int Do,

@@ -35,6 +35,8 @@ SIGNATURES = {
     "dram_maxpool3d_2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_upsample_trilinear_ac_fwd": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "dram_upsample_trilinear_ac_bwd": (I, [P, P, I, I, I, I, I, I, I, I, P]),
+    "dram_upsample_trilinear_ac_bwd_ws_bytes": (Z, [I, I, I, I, I, I, I, I]),
+    "dram_upsample_trilinear_ac_bwd_ws": (I, [P, P, P, Z, I, I, I, I, I, I, I, I, P]),
     "dram_crop_concat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dram_crop_concat_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "dram_conv3d_k1_fwd": (I, [P, P, P, P, I, I, I, L, P]),

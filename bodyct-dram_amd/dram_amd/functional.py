@@ -7,6 +7,7 @@ There is no fallback: CPU tensors raise.
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -410,6 +411,10 @@ def max_pool3d_2(x):
 
 
 # --------------------------------------------------------------------------- trilinear resize
+# workspace cap of the two-stage trilinear backward (the z-reduced intermediate of a group of planes)
+TRI_BWD_WS_CAP = int(os.environ.get("DRAM_TRI_WS_MB", "1024")) << 20
+
+
 class TrilinearACFn(Function):
     """nn.Upsample(mode='trilinear', align_corners=True) (reference parts.py:149, models.py:146)."""
 
@@ -429,7 +434,10 @@ class TrilinearACFn(Function):
         N, C, D, H, W, Do, Ho, Wo = ctx.shapes
         dy = _chk(dy, "upsample grad_output", 5)
         dx = torch.empty((N, C, D, H, W), dtype=torch.float32, device=dy.device)
-        call("dram_upsample_trilinear_ac_bwd", _p(dy), _p(dx), N, C, D, H, W, Do, Ho, Wo, _stream())
+        full = _lib.lib.dram_upsample_trilinear_ac_bwd_ws_bytes(N, C, D, H, W, Do, Ho, Wo)
+        ws = _ws(min(full, TRI_BWD_WS_CAP), dy.device) if full else None
+        call("dram_upsample_trilinear_ac_bwd_ws", _p(dy), _p(dx), _p(ws), ws.numel() if ws is not None else 0,
+             N, C, D, H, W, Do, Ho, Wo, _stream())
         return dx, None
 
 

@@ -146,6 +146,12 @@ int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, int C, int D
                                    int Do, int Ho, int Wo, void* stream);
 int dram_upsample_trilinear_ac_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W,
                                    int Do, int Ho, int Wo, void* stream);
+/* The same adjoint in two stages (reduce z with 16-byte loads, then y/x) through a workspace: any size >= 8
+ * planes of D*Ho*Wo floats works (planes are processed in groups that fit); _ws_bytes returns the size for all
+ * planes at once, 0 when the shape does not qualify (then, or with too small a workspace, this is _bwd). */
+size_t dram_upsample_trilinear_ac_bwd_ws_bytes(int N, int C, int D, int H, int W, int Do, int Ho, int Wo);
+int dram_upsample_trilinear_ac_bwd_ws(const float* dy, float* dx, void* ws, size_t ws_bytes, int N, int C,
+                                      int D, int H, int W, int Do, int Ho, int Wo, void* stream);
 
 /* ---- crop_concat_5d (parts.py:37-46) ----
  * out[N,C1+C2,D,H,W] = cat(t1[N,C1,D,H,W], t2[N,C2,D2,H2,W2][..., oz:oz+D, oy:oy+H, ox:ox+W]). */
