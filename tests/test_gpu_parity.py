@@ -221,7 +221,7 @@ def test_batchnorm_statistics_with_large_mean():
 
 
 # ------------------------------------------------------------------ pool / resize / head
-@pytest.mark.parametrize("shape", [(2, 3, 6, 10, 12), (1, 4, 7, 9, 11), (2, 2, 16, 16, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 6, 10, 12), (1, 4, 7, 9, 11), (2, 2, 16, 16, 32), (1, 2, 7, 9, 8), (1, 1, 2, 3, 4)])
 def test_maxpool_with_ties(shape):
     from dram_amd import functional as HF
     x = torch.relu(torch.randn(*shape, generator=g(21)))     # ~50 % zeros: ties in most windows
