@@ -5,8 +5,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NACC>
+template <int NACC, int PRIO = 0>
 __global__ __launch_bounds__(512) void k32(float* out, int iters, float a0, float b0) {
+    if (PRIO && threadIdx.x >= 256) __builtin_amdgcn_s_setprio(2);   // second wave of each SIMD issues first
     f32x16 acc[NACC];
     for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float a = a0 + threadIdx.x, b = b0 - threadIdx.x;
@@ -56,6 +57,9 @@ int main() {
     float* out; (void)hipMalloc(&out, 256 * 512 * 4);
     run("32x32x2  4 accumulators", k32<4>, 512, 4096.0, 4, out);
     run("32x32x2  4 accumulators", k32<4>, 256, 4096.0, 4, out);
+    run("32x32x2  4 acc, wave priority", k32<4, 1>, 512, 4096.0, 4, out);
+    run("32x32x2  8 accumulators", k32<8>, 512, 4096.0, 8, out);
+    run("32x32x2  2 accumulators", k32<2>, 512, 4096.0, 2, out);
     run("16x16x4  4 accumulators", k16<4>, 512, 2048.0, 4, out);
     run("16x16x4 27 accumulators", k16<27>, 512, 2048.0, 27, out);
     run("16x16x4 27 accumulators", k16<27>, 256, 2048.0, 27, out);
