@@ -290,6 +290,222 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / backward-data with Winograd F(2,3) along z (exact fp32 arithmetic, 2/3 of the MFMAs).
+//
+// For the two output planes z0, z0+1 of a box and its four input planes d0..d3 = x[z0-1..z0+2]
+//     y[z0]   = g0 d0 + g1 d1 + g2 d2
+//     y[z0+1] = g0 d1 + g1 d2 + g2 d3                        (g = the three z taps of one (ky,kx) column)
+// are computed as  m0 = (d0-d2) g0,  m1 = (d1+d2)(g0+g1+g2)/2,  m2 = (d2-d1)(g0-g1+g2)/2,  m3 = (d1-d3) g2,
+//     y[z0] = m0+m1+m2,  y[z0+1] = m1-m2-m3:
+// four products per (ci, ky, kx) instead of six.  In GEMM terms: four independent implicit GEMMs (one per
+// transformed plane xi) with K = Cin x 9 in-plane taps, N = the (y,x) positions of the plane pair, whose
+// accumulators are combined in registers in the epilogue.  Why z and not x: the transformed input tile
+// (4 planes) is exactly as large as the raw halo (BZ + 2 = 4 planes) and the transform is element-wise
+// between planes -- a thread loads its (y,x) position from the 4 planes, combines, stores; no shuffles, no
+// change to the coalesced row loads, no change to the lane <-> voxel mapping of operands and stores.
+// The transformed filters (36 = 9 x 4 matrices instead of 27) are prepared by pack_weights_wz_kernel.
+// LDS: input tile double-buffered (2 x 13 KB), filter tile (36 x KC x 64 floats = 36 KB) single-buffered
+// (two barriers per chunk) so that two blocks still share a CU.
+template <int BX, int BY, int COT>
+struct FwdWzGeom {
+    static constexpr int HX = BX + 2, HY = BY + 2;
+    static constexpr int HP = HX * HY;                  // halo positions of one plane
+    static constexpr int PK = 4 * HP;                   // floats per input channel: 4 transformed planes
+    static constexpr int COB = 32 * COT;
+    static constexpr int WROWS = 36 * KC;
+    static constexpr int WSLOTS = WROWS * COB / 4;
+    static constexpr int WPASS = (WSLOTS + 255) / 256;
+    static constexpr int IN_STAGE = KC * PK;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * IN_STAGE + WROWS * COB) * sizeof(float);
+};
+
+template <int BX, int BY, int COT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
+    static_assert(BX * BY == 128, "block covers 128 (y,x) positions of two z planes");
+    using G = FwdWzGeom<BX, BY, COT>;
+    constexpr int HX = G::HX, HP = G::HP, PK = G::PK, COB = G::COB;
+    constexpr int WSLOTS = G::WSLOTS, WPASS = G::WPASS, IN_STAGE = G::IN_STAGE;
+    static_assert(HP <= 256, "one halo position per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lwt = lds + 2 * IN_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, co tile), co tile fastest
+    const int co0 = (b % a.co_tiles) * COB; b /= a.co_tiles;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    const int n = b / a.nbz;
+    const int x0 = bx * BX, y0 = by * BY, z0 = bz * 2;
+    const int D = a.D, H = a.H, W = a.W;
+    const int S = D * H * W;
+    const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
+
+    // staging role: thread = one (y,x) halo position, the 4 input planes z0-1 .. z0+2 of it
+    u32x4 off1, off2;
+    {
+        const int hx = tid % HX, hy = tid / HX;
+        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+        const bool okp = tid < HP && gx >= 0 && gx < W && gy >= 0 && gy < H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gz = z0 - 1 + q;
+            const bool ok = okp && gz >= 0 && gz < D;
+            off1[q] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+            off2[q] = ok ? 4u * (unsigned)(((gz + a.src.oz) * a.src.H2 + gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
+        }
+    }
+    const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
+    const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
+
+    f32x16 acc[COT][4];
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+    const int j = lane & 31, kh = lane >> 5;
+    const int pos = 32 * wave + j;                   // this lane's (y,x) position inside the box
+    const int vx = pos % BX, vy = pos / BX;
+    const int bbase = kh * PK + vy * HX + vx;
+    const int abase = kh * COB + j;
+
+    // transformed filters wz[(ky*3+kx)*4 + xi][Cin][Cout]: a chunk's [36*KC rows][COB] tile, 16-byte slots
+    const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 36u * (unsigned)a.Cin * (unsigned)a.Cout * 4u);
+    const unsigned tap_stride = 4u * (unsigned)a.Cin * (unsigned)a.Cout;
+    unsigned wvoff[WPASS];
+    int wkc[WPASS];
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) {
+        const int f = p * 256 + tid;
+        const int row = f / (COB / 4), c4 = f % (COB / 4);
+        const int tap = row / KC;
+        wkc[p] = row % KC;
+        wvoff[p] = f < WSLOTS ? (unsigned)tap * tap_stride + 4u * (unsigned)(wkc[p] * a.Cout + co0 + 4 * c4) : OOB;
+    }
+
+    float rin[KC][4];
+    f32x4 rw[WPASS];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int ci = c0 + kc;                      // wave-uniform
+            const bool first = ci < a.src.C1;
+            const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
+            const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;   // 0 records: all zeros
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(plane), bytes);
+            const u32x4 off = first ? off1 : off2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rin[kc][q] = buf_load(srd, off[q], 0);
+        }
+        const unsigned cbase = 4u * (unsigned)c0 * (unsigned)a.Cout;
+        if (c0 + KC <= a.Cin) {
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) rw[p] = buf_load4(wsrd, wvoff[p] + cbase, 0);
+        } else {
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) rw[p] = buf_load4(wsrd, (c0 + wkc[p]) < a.Cin ? wvoff[p] + cbase : OOB, 0);
+        }
+    };
+    auto store_in = [&](float* lin) {     // B^T d of the four planes
+        if (tid < HP) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const float d0 = rin[kc][0], d1 = rin[kc][1], d2 = rin[kc][2], d3 = rin[kc][3];
+                float* o = lin + kc * PK + tid;
+                o[0] = d0 - d2;
+                o[HP] = d1 + d2;
+                o[2 * HP] = d2 - d1;
+                o[3 * HP] = d1 - d3;
+            }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) {
+            const int f = p * 256 + tid;
+            if (WPASS * 256 == WSLOTS || f < WSLOTS) *reinterpret_cast<f32x4*>(lwt + 4 * f) = rw[p];
+        }
+    };
+    auto compute = [&](const float* lin) {
+        constexpr int NS = 36 * (KC / 2);   // k-steps of this chunk: (ky,kx) x xi x channel pairs
+        float av[2][COT], bv[2];
+#pragma unroll
+        for (int s = 0; s <= NS; ++s) {
+            if (s < NS) {
+                const int t36 = s / (KC / 2), kk = s % (KC / 2);
+                const int tap9 = t36 / 4, xi = t36 % 4;
+                const int toff = xi * HP + (tap9 / 3) * HX + tap9 % 3;
+#pragma unroll
+                for (int c = 0; c < COT; ++c) av[s & 1][c] = lwt[abase + (t36 * KC + 2 * kk) * COB + 32 * c];
+                bv[s & 1] = lin[bbase + 2 * kk * PK + toff];
+            }
+            if (s > 0) {
+                const int xi = ((s - 1) / (KC / 2)) % 4;
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+                    acc[c][xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(s - 1) & 1][c], bv[(s - 1) & 1], acc[c][xi], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, COT + 1, 0);   // DS reads of step s ...
+            __builtin_amdgcn_sched_group_barrier(0x008, COT, 0);       // ... then MFMAs of step s-1
+        }
+    };
+
+    load_chunk(0);
+    store_in(lds);
+    store_w();
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+        const bool has_next = (c0 + KC) < a.Cin;
+        if (has_next) load_chunk(c0 + KC);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(lds + cur * IN_STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+            store_in(lds + (cur ^ 1) * IN_STAGE);
+            __syncthreads();            // every wave is done reading the filter tile of this chunk
+            store_w();
+            __syncthreads();
+        }
+        cur ^= 1;
+    }
+
+    // ---- epilogue: A^T m per accumulator element, then the same stores as the direct kernel ----
+    const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
+    const int gx = x0 + vx, gy = y0 + vy;
+    if (gx < W && gy < H) {
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            const int gz = z0 + zz;
+            if (gz >= D) continue;
+            const int sp1 = (gz * H + gy) * W + gx;
+            const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (co < a.Cout) {
+                        float val = zz == 0 ? (acc[c][0][r] + acc[c][1][r]) + acc[c][2][r]
+                                            : (acc[c][1][r] - acc[c][2][r]) - acc[c][3][r];
+                        if (a.bias) val += a.bias[co];
+                        if (co < a.dst.C1)
+                            a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
+                        else
+                            a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct WgradArgs {
     CatView src;      // x (possibly a virtual concatenation)
     const float* dy;  // [N][Cout][D][H][W]
@@ -822,6 +1038,62 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// Transformed filters of the Winograd-z kernel: wz[(ky*3+kx)*4 + xi][ci'][co'] = (G g)[xi] of the three z taps g of
+// column (ky,kx); mode as above (1: the transposed convolution's filter, taps flipped, channel roles swapped).
+__global__ void pack_weights_wz_kernel(const float* __restrict__ w, float* __restrict__ wz, int Cout, int Cin, int mode) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t E = (int64_t)36 * Cin * Cout;
+    if (e >= E) return;
+    const int t36 = (int)(e / ((int64_t)Cout * Cin));
+    const int tap9 = t36 / 4, xi = t36 % 4;
+    int co, ci;
+    if (mode == 0) { co = e % Cout; ci = (e / Cout) % Cin; }
+    else { ci = e % Cin; co = (e / Cin) % Cout; }
+    const float* g = w + ((size_t)co * Cin + ci) * 27;
+    float g0, g1, g2;
+    if (mode == 0) { g0 = g[tap9]; g1 = g[9 + tap9]; g2 = g[18 + tap9]; }
+    else { g0 = g[18 + (8 - tap9)]; g1 = g[9 + (8 - tap9)]; g2 = g[8 - tap9]; }
+    wz[e] = xi == 0 ? g0 : xi == 1 ? 0.5f * ((g0 + g1) + g2) : xi == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int BX, int BY, int COT>
+static int launch_fwd_wz_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
+    using G = FwdWzGeom<BX, BY, COT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_fwd_wz_kernel<BX, BY, COT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("conv3d_k3_fwd(wz): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DRAM_EHIP;
+        }
+        attr_done = true;
+    }
+    a.co_tiles = cdiv(a.Cout, 32 * COT);
+    const int64_t total = (int64_t)nblk * a.co_tiles;
+    if (total > 0x7fffffffLL) {
+        set_error("conv3d_k3_fwd: grid too large");
+        return DRAM_EINVAL;
+    }
+    hipLaunchKernelGGL((conv3d_k3_fwd_wz_kernel<BX, BY, COT>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
+    return check_launch("conv3d_k3_fwd(wz)");
+}
+
+template <int BX, int BY>
+static int launch_fwd_wz(ConvArgs& a, hipStream_t st) {
+    a.nbx = cdiv(a.W, BX);
+    a.nby = cdiv(a.H, BY);
+    a.nbz = cdiv(a.D, 2);
+    const int64_t nblk = (int64_t)a.N * a.nbx * a.nby * a.nbz;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d_k3_fwd: grid too large");
+        return DRAM_EINVAL;
+    }
+    if (a.Cout <= 32) return launch_fwd_wz_cot<BX, BY, 1>(a, (unsigned)nblk, st);
+    return launch_fwd_wz_cot<BX, BY, 2>(a, (unsigned)nblk, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int BX, int BY, int BZ, int COT>
 static int launch_fwd_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
@@ -877,7 +1149,23 @@ static int pick_box(int D, int H, int W, const int (*boxes)[3], int nboxes, cons
     return best;
 }
 
+// The Winograd-z kernel serves every layer with enough input channels to amortise its filter tile; the first
+// layer (Cin = 1) and DRAM_CONV_DIRECT=1 (experiments, A/B tests) use the direct kernel.
+static bool use_wz(const ConvArgs& a) {
+    static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
+    return !direct && a.Cin >= 8 && a.D >= 2;
+}
+
 static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
+    if (use_wz(a)) {
+        static const int boxes2[3][3] = {{32, 4, 1}, {16, 8, 1}, {8, 16, 1}};
+        a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
+        switch (pick_box(1, a.H, a.W, boxes2, 3, "DRAM_FWD_BX")) {
+            case 0: return launch_fwd_wz<32, 4>(a, st);
+            case 1: return launch_fwd_wz<16, 8>(a, st);
+            default: return launch_fwd_wz<8, 16>(a, st);
+        }
+    }
     static const int boxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
     switch (pick_box(a.D, a.H, a.W, boxes, 3, "DRAM_FWD_BX")) {
         case 0: return launch_fwd<32, 4, 2>(a, st);
@@ -983,12 +1271,20 @@ static int check_cat(const char* who, const CatView& v, int D, int H, int W) {
 
 using namespace dram;
 
+extern "C" size_t dram_conv3d_k3_packed_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)(27 + 36) * Cin * Cout;
+}
+
 extern "C" int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, int Cin, int mode, void* stream) {
     DRAM_REQUIRE(w && wt, "conv3d_k3_pack_weights: null pointer");
     DRAM_REQUIRE(Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "conv3d_k3_pack_weights: bad arguments");
     const int64_t E = (int64_t)27 * Cin * Cout;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, (hipStream_t)stream, w, wt,
                        Cout, Cin, mode);
+    const int64_t Ez = (int64_t)36 * Cin * Cout;
+    hipLaunchKernelGGL(pack_weights_wz_kernel, dim3((unsigned)cdiv64(Ez, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wt + E, Cout, Cin, mode);
     return check_launch("conv3d_k3_pack_weights");
 }
 

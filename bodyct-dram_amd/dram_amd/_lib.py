@@ -16,6 +16,7 @@ P, I, L, F, Z = c_void_p, c_int, c_int64, c_float, c_size_t
 SIGNATURES = {
     "dram_last_error": (c_char_p, []),
     "dram_abi_version": (I, []),
+    "dram_conv3d_k3_packed_floats": (Z, [I, I]),
     "dram_conv3d_k3_pack_weights": (I, [P, P, I, I, I, P]),
     "dram_conv3d_k3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "dram_conv3d_k3_fwd_cat": (I, [P, I, P, I, I, I, I, I, I, I, P, P, P, I, I, I, I, I, P]),

@@ -63,11 +63,15 @@ def _pick_box(dhw, boxes):
     return min(boxes, key=vol)
 
 
-def conv_fwd_kernel_name(dhw, Cout):
-    """Name of the conv3d_k3_fwd_kernel instantiation the library picks (csrc/conv3d_k3.hip
-    conv_fwd_dispatch / launch_fwd), as rocprofv3 prints it."""
+def conv_fwd_kernel_name(dhw, Cout, Cin):
+    """Name of the forward / backward-data kernel instantiation the library picks (csrc/conv3d_k3.hip
+    conv_fwd_dispatch), as rocprofv3 prints it."""
+    cot = 1 if Cout <= 32 else 2
+    if Cin >= 8 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):
+        box = _pick_box((1, dhw[1], dhw[2]), [(32, 4, 1), (16, 8, 1), (8, 16, 1)])
+        return f"conv3d_k3_fwd_wz_kernel<{box[0]}, {box[1]}, {cot}>"
     box = _pick_box(dhw, [(32, 4, 2), (16, 4, 4), (8, 8, 4)])
-    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {1 if Cout <= 32 else 2}>"
+    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {cot}>"
 
 
 def conv_wgrad_kernel_name(dhw, Cout, Cin=None):
@@ -107,7 +111,7 @@ def crop_offsets(small, big):
 # --------------------------------------------------------------------------- conv 3x3x3
 def _pack(w, mode):
     co, ci = w.shape[0], w.shape[1]
-    wt = torch.empty(27 * ci * co, dtype=torch.float32, device=w.device)
+    wt = torch.empty(_lib.lib.dram_conv3d_k3_packed_floats(co, ci), dtype=torch.float32, device=w.device)
     call("dram_conv3d_k3_pack_weights", _p(w), _p(wt), co, ci, mode, _stream())
     return wt
 
@@ -141,7 +145,7 @@ class Conv3dK3Fn(Function):
         wt = _pack(w, 0)
         y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x1.device)
         vox = N * D * H * W
-        _timed_call(conv_fwd_kernel_name((D, H, W), Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+        _timed_call(conv_fwd_kernel_name((D, H, W), Co, Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                     "dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
                     _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
         ctx.save_for_backward(x1, x2, w)
@@ -168,7 +172,7 @@ class Conv3dK3Fn(Function):
                 full = (D2, H2, W2) == (D, H, W)
                 dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
             vox = N * D * H * W
-            _timed_call(conv_fwd_kernel_name((D, H, W), Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                         _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
             if not need1:

@@ -44,14 +44,17 @@ int dram_abi_version(void);
 
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 (nn.Conv3d at parts.py:95,105,133,142,177,185) ----
  *
- * The kernels take the filter in a GEMM-friendly layout wt[27][Cin][Cout]
- * (tap-major, Cout fastest).  dram_conv3d_k3_pack_weights builds it from the
- * reference's [Cout][Cin][3][3][3] parameter:
+ * The kernels take the filter in a packed, GEMM-friendly form of dram_conv3d_k3_packed_floats(Cout, Cin)
+ * floats that dram_conv3d_k3_pack_weights builds from the reference's [Cout][Cin][3][3][3] parameter:
+ *   wt[27][Cin][Cout] (tap-major, Cout fastest) for the direct kernel, followed by
+ *   wz[9*4][Cin][Cout], the Winograd F(2,3)-along-z transformed filters ((ky,kx) column x 4 transformed taps).
  *   mode 0 (forward):  wt[t][ci][co] = w[co][ci][t]
  *   mode 1 (backward-data): wt[t][co][ci] = w[co][ci][26-t], i.e. the filter
  *          of the transposed convolution -- run dram_conv3d_k3_fwd on dy with
  *          Cin/Cout swapped to obtain dx.
+ * Which kernel runs is the library's choice (Winograd-z for Cin >= 8; exact fp32 arithmetic either way).
  */
+size_t dram_conv3d_k3_packed_floats(int Cout, int Cin);
 int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, int Cin, int mode, void* stream);
 
 /* y[N,Cout,D,H,W] = conv3d(x[N,Cin,D,H,W], w) (+ bias[Cout] when bias != NULL). */
