@@ -922,6 +922,242 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward-weights with the transpose of Winograd F(2,3) along z (exact fp32 arithmetic, 2/3 of the MFMAs).
+// For a plane pair (z0, z0+1) with gradients e0, e1 and inputs d0..d3 = x[z0-1..z0+2] the three z taps of a
+// (ky,kx) column receive  dg0 = e0 d0 + e1 d1,  dg1 = e0 d1 + e1 d2,  dg2 = e0 d2 + e1 d3  (6 products).
+// Transposing the bilinear algorithm of the forward kernel:
+//     p0 = e0 (d0-d2),  p1 = (e0+e1)(d1+d2),  p2 = (e0-e1)(d2-d1),  p3 = -e1 (d1-d3)      (4 products)
+//     dg0 = p0 + (p1+p2)/2,   dg1 = (p1-p2)/2,   dg2 = (p1+p2)/2 + p3.
+// So: four GEMMs (one per transformed plane xi) dP[xi][co][ci][ky,kx] += E_xi[co][pos] * T_xi[ci][pos+(ky,kx)] with
+// K = the (y,x) positions of the plane pair; 9 x 4 = 36 accumulators of 16x16 per wave instead of 27, and 36
+// MFMAs per 2 voxels instead of 54.  Staging as in the 16-byte kernel above, except that a thread fetches its
+// slot from both (dY) / all four (X) planes and stores the transformed planes.
+template <int BX, int BY, int COS, int CIT>
+struct WgradWzGeom {
+    static constexpr int T = 512;
+    static constexpr int POS = BX * BY;                 // positions of the plane pair = K per box and xi
+    static constexpr int RA = 4 * POS + 2;              // dY channel stride (4 planes): == 2 (mod 32) -> conflict-free A reads
+    static constexpr int HY = BY + 2;
+    static constexpr int HXP = BX + 8;                  // padded halo row: [3 pad][left][BX interior][right][3 pad]
+    static constexpr int PLX = HY * HXP;                // one transformed X plane
+    static constexpr int PB = PadTo2Mod32<4 * PLX>::value;
+    static constexpr int CO_B = 16 * COS, CI_B = 16 * CIT;
+    static constexpr int DY_TPC = POS / 4, DY_CPP = T / DY_TPC, DYP = (CO_B + DY_CPP - 1) / DY_CPP;
+    static constexpr int XI_TPC = HY * (BX / 4), XI_CPP = T / XI_TPC, XIP = (CI_B + XI_CPP - 1) / XI_CPP;
+    static constexpr int XE_TPC = HY * 2, XE_CPP = T / XE_TPC, XEP = (CI_B + XE_CPP - 1) / XE_CPP;
+    static constexpr size_t LDS_BYTES = (size_t)(CO_B * RA + CI_B * PB) * sizeof(float);
+};
+
+template <int BX, int BY, int COS, int CIT>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a) {
+    using G = WgradWzGeom<BX, BY, COS, CIT>;
+    constexpr int POS = G::POS, RA = G::RA, HXP = G::HXP, PLX = G::PLX, PB = G::PB;
+    constexpr int CO_B = G::CO_B, CI_B = G::CI_B, DYP = G::DYP, XIP = G::XIP, XEP = G::XEP;
+    constexpr int DY_TPC = G::DY_TPC, DY_CPP = G::DY_CPP, XI_TPC = G::XI_TPC, XI_CPP = G::XI_CPP, XE_TPC = G::XE_TPC, XE_CPP = G::XE_CPP;
+    static_assert(COS * CIT == 8 && BX % 4 == 0 && POS % 8 == 0 && PB % 2 == 0 && RA % 2 == 0 && DY_CPP >= 1 && XI_CPP >= 1 &&
+                      XE_CPP >= 1, "block geometry");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldy = lds;             // [CO_B][4][POS] (+2)
+    float* lx = lds + CO_B * RA;  // [CI_B][4][HY][HXP]; halo x index h of a row at column h+3
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % COS, wci = wave / COS;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = b % a.ci_tiles; b /= a.ci_tiles;
+    const int co_t = b % a.co_tiles;
+    const int sp = b / a.co_tiles;
+    const int ci0 = ci_t * CI_B, co0 = co_t * CO_B;
+    const int D = a.D, H = a.H, W = a.W;
+    const int S = D * H * W;
+    const bool use2 = a.src.p2 != nullptr && ci0 >= a.src.C1;
+    const int Hs = use2 ? a.src.H2 : H, Ws = use2 ? a.src.W2 : W;
+    const int Ss = use2 ? a.src.D2 * a.src.H2 * a.src.W2 : S;
+    const int oz = use2 ? a.src.oz : 0, oy = use2 ? a.src.oy : 0, ox = use2 ? a.src.ox : 0;
+    const int Cs = use2 ? a.src.C2 : a.src.C1;
+    const int cs0 = use2 ? ci0 - a.src.C1 : ci0;
+    const float* xs = use2 ? a.src.p2 : a.src.p1;
+    const unsigned S4 = 4u * (unsigned)S, Ss4 = 4u * (unsigned)Ss;
+    const unsigned zs4 = 4u * (unsigned)(H * W), zss4 = 4u * (unsigned)(Hs * Ws);   // plane strides in bytes
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int i = lane & 15, k = lane >> 4;
+
+    f32x4 rdy[DYP][2];
+    f32x4 rxi[XIP][4];
+    float rxe[XEP][4];
+
+    // thread-constant slot roles (see conv3d_k3_wgrad_vec_kernel)
+    const int d_c = tid / DY_TPC, d_v = 4 * (tid % DY_TPC);
+    const int d_vx = d_v % BX, d_vy = d_v / BX;
+    const bool d_act = d_c < DY_CPP;
+    const unsigned d_rel = (unsigned)(co0 + d_c) * S4 + 4u * (unsigned)(d_vy * W + d_vx);
+    const int i_c = tid / XI_TPC, i_r = (tid % XI_TPC) / (BX / 4), i_j = tid % (BX / 4);     // i_r = halo row
+    const bool i_act = i_c < XI_CPP;
+    const unsigned i_rel = (unsigned)(cs0 + i_c) * Ss4 + 4u * (unsigned)(i_r * Ws + 4 * i_j);
+    const int e_c = tid / XE_TPC, e_r = (tid % XE_TPC) / 2, e_side = tid % 2;
+    const bool e_act = e_c < XE_CPP;
+    const unsigned e_rel = (unsigned)(cs0 + e_c) * Ss4 + 4u * (unsigned)(e_r * Ws + (e_side ? BX : -1));
+
+    auto load_box = [&](int box) {
+        int bb = box;
+        const int bx = bb % a.nbx; bb /= a.nbx;
+        const int by = bb % a.nby; bb /= a.nby;
+        const int bz = bb % a.nbz;
+        const int n = bb / a.nbz;
+        const int x0 = bx * BX, y0 = by * BY, z0 = 2 * bz;
+        {   // dY, planes z0 and z0+1 (full rows in x: W % BX == 0)
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), (unsigned)a.Cout * S4);
+            const bool ok = d_act && (y0 + d_vy) < H;
+            const bool ok1 = ok && (z0 + 1) < D;
+            unsigned run = 4u * (unsigned)((z0 * H + y0) * W + x0) + d_rel;
+            const unsigned inc = (unsigned)DY_CPP * S4;
+#pragma unroll
+            for (int p = 0; p < DYP; ++p) {
+                const bool in = DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B;
+                rdy[p][0] = buf_load4(srd, (ok && in) ? run : OOB, 0);
+                rdy[p][1] = buf_load4(srd, (ok1 && in) ? run + zs4 : OOB, 0);
+                run += inc;
+            }
+        }
+        {   // X halo rows of the four planes z0-1 .. z0+2
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(xs + (size_t)n * Cs * Ss), (unsigned)Cs * Ss4);
+            const unsigned origin = 4u * (unsigned)(((z0 - 1 + oz) * Hs + (y0 - 1 + oy)) * Ws + x0 + ox);   // may wrap: invalid rows are masked
+            {
+                const bool okr = i_act && (unsigned)(y0 - 1 + i_r) < (unsigned)H;
+                unsigned run = origin + i_rel;
+                const unsigned inc = (unsigned)XI_CPP * Ss4;
+#pragma unroll
+                for (int p = 0; p < XIP; ++p) {
+                    const bool in = okr && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rxi[p][q] = buf_load4(srd, (in && (unsigned)(z0 - 1 + q) < (unsigned)D) ? run + (unsigned)q * zss4 : OOB, 0);
+                    run += inc;
+                }
+            }
+            {
+                const bool okr = e_act && (unsigned)(y0 - 1 + e_r) < (unsigned)H && (e_side ? (x0 + BX) < W : x0 > 0);
+                unsigned run = origin + e_rel;
+                const unsigned inc = (unsigned)XE_CPP * Ss4;
+#pragma unroll
+                for (int p = 0; p < XEP; ++p) {
+                    const bool in = okr && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rxe[p][q] = buf_load(srd, (in && (unsigned)(z0 - 1 + q) < (unsigned)D) ? run + (unsigned)q * zss4 : OOB, 0);
+                    run += inc;
+                }
+            }
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int p = 0; p < DYP; ++p)
+            if (d_act && (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B)) {
+                const f32x4 e0 = rdy[p][0], e1 = rdy[p][1];
+                const f32x4 pl[4] = {e0, e0 + e1, e0 - e1, -e1};
+                float* d = ldy + (d_c + p * DY_CPP) * RA + d_v;        // 8-byte aligned
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    *reinterpret_cast<f32x2*>(d + q * POS) = f32x2{pl[q][0], pl[q][1]};
+                    *reinterpret_cast<f32x2*>(d + q * POS + 2) = f32x2{pl[q][2], pl[q][3]};
+                }
+            }
+#pragma unroll
+        for (int p = 0; p < XIP; ++p)
+            if (i_act && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B)) {
+                const f32x4 d0 = rxi[p][0], d1 = rxi[p][1], d2 = rxi[p][2], d3 = rxi[p][3];
+                const f32x4 pl[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+                float* d = lx + (i_c + p * XI_CPP) * PB + i_r * HXP + 4 + 4 * i_j;       // 8-byte aligned
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    *reinterpret_cast<f32x2*>(d + q * PLX) = f32x2{pl[q][0], pl[q][1]};
+                    *reinterpret_cast<f32x2*>(d + q * PLX + 2) = f32x2{pl[q][2], pl[q][3]};
+                }
+            }
+#pragma unroll
+        for (int p = 0; p < XEP; ++p)
+            if (e_act && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B)) {
+                const float d0 = rxe[p][0], d1 = rxe[p][1], d2 = rxe[p][2], d3 = rxe[p][3];
+                float* d = lx + (e_c + p * XE_CPP) * PB + e_r * HXP + (e_side ? BX + 4 : 3);
+                d[0] = d0 - d2;
+                d[PLX] = d1 + d2;
+                d[2 * PLX] = d2 - d1;
+                d[3 * PLX] = d1 - d3;
+            }
+    };
+    auto compute = [&]() {
+        const float* ap = ldy + (wco * 16 + i) * RA + k;
+        const float* bp = lx + (wci * 16 + i) * PB + k + 3;
+        constexpr int NU = POS;     // (POS/4 k-steps) x (4 planes)
+        float av[2], bv[2][9];
+        // one operand read of step u beside each MFMA of step u-1
+#pragma unroll
+        for (int u = 0; u <= NU; ++u) {
+            const int s = u / 4, xi = u % 4;
+            const int x4 = s % (BX / 4), vy = s / (BX / 4);
+            const float* bq = bp + xi * PLX + vy * HXP + 4 * x4;
+            const int xp = (u - 1) % 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (u < NU) {
+                    if (tap == 0) av[u & 1] = ap[xi * POS + 4 * s];
+                    bv[u & 1][tap] = bq[(tap / 3) * HXP + tap % 3];
+                }
+                if (u > 0)
+                    acc[tap][xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(u - 1) & 1], bv[(u - 1) & 1][tap], acc[tap][xp], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (sp < a.nboxes) {
+        load_box(sp);
+        store_box();
+    }
+    __syncthreads();
+    for (int box = sp; box < a.nboxes; box += a.split) {
+        const bool has_next = (box + a.split) < a.nboxes;
+        if (has_next) load_box(box + a.split);
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+            __syncthreads();
+            store_box();
+            __syncthreads();
+        }
+    }
+
+    // G^T p per accumulator element -> the three z taps of each (ky,kx) column
+    const int ci = ci0 + wci * 16 + i;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wco * 16 + 4 * k + r;
+            if (co < a.Cout) {
+                float* o = a.slabs + (((size_t)sp * a.Cout + co) * a.Cin + ci) * 27;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float p0 = acc[tap][0][r], p1 = acc[tap][1][r], p2 = acc[tap][2][r], p3 = acc[tap][3][r];
+                    const float h = 0.5f * (p1 + p2);
+                    o[tap] = p0 + h;
+                    o[9 + tap] = 0.5f * (p1 - p2);
+                    o[18 + tap] = h + p3;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weights of the FIRST layer (Cin == 1, e.g. DC3D ds_modules.0 conv 1->32).  The generic
 // kernel would run its 16/32-wide input-channel tile 1/32 full; here the 27 taps of the single input
 // channel play the role of the GEMM's N dimension instead:
@@ -1176,17 +1412,30 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
 
 struct WgradPlan {
     int variant;  // 0: block = 64 co x 32 ci (Cout <= 64);  1: block = 128 co x 16 ci
+    int wz;       // 1: Winograd-z kernel (boxes = bx x by positions of a plane pair)
     int bx, by, bz, nbx, nby, nbz, nboxes, ci_tiles, co_tiles, split;
 };
 
-static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W) {
+static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C1 = 0) {
     WgradPlan p;
     p.variant = Cout > 64 ? 1 : 0;
+    p.wz = 0;
+    {   // Winograd-z: rows must be full boxes along x and a channel tile must lie inside one source tensor
+        static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
+        const int ci_b = p.variant == 1 ? 16 : 32;
+        const int bx = (W % 16 == 0) ? 16 : ((W % 8 == 0) ? 8 : 0);
+        if (!direct && bx && D >= 2 && (C1 == 0 || C1 % ci_b == 0)) {
+            p.wz = 1;
+            p.bx = bx; p.by = bx == 16 ? 2 : 4; p.bz = 2;
+        }
+    }
+    if (!p.wz) {
     // ties go to the 16-wide box: its X halo (18x4x4 = 288 elements per 64 voxels, against 408 for 34x4x3)
     // needs the fewest staging loads (measured +2.6 % at 128^3 / 64^3 / 32^3)
     static const int boxes[3][3] = {{16, 2, 2}, {32, 2, 1}, {8, 4, 2}};
     const int bi = pick_box(D, H, W, boxes, 3, "DRAM_WGRAD_BX");
     p.bx = boxes[bi][0]; p.by = boxes[bi][1]; p.bz = boxes[bi][2];
+    }
     p.nbx = cdiv(W, p.bx); p.nby = cdiv(H, p.by); p.nbz = cdiv(D, p.bz);
     const int64_t nb = (int64_t)N * p.nbx * p.nby * p.nbz;
     p.nboxes = (int)nb;
@@ -1231,6 +1480,24 @@ static int launch_wgrad_vec(WgradArgs& a, hipStream_t st) {
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     hipLaunchKernelGGL((conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad(vec)");
+}
+
+template <int BX, int BY, int COS, int CIT>
+static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
+    using G = WgradWzGeom<BX, BY, COS, CIT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DRAM_EHIP;
+        }
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
+    return check_launch("conv3d_k3_wgrad(wz)");
 }
 
 template <int BX, int BY, int BZ, int COS, int CIT>
@@ -1335,8 +1602,9 @@ extern "C" size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D,
         const int64_t nboxes = (int64_t)N * cdiv(W, 32) * cdiv(H, 4) * cdiv(D, 2);
         return (size_t)4 * wgrad_c1_blocks((int)(nboxes < 0x7fffffff ? nboxes : 0x7fffffff)) * Cout * 27 * sizeof(float);
     }
-    const WgradPlan p = wgrad_plan(N, Cin, Cout, D, H, W);
-    return (size_t)p.split * Cout * Cin * 27 * sizeof(float);
+    // the split depends on whether a virtual-concat input lets the Winograd kernel run: size for the larger
+    const WgradPlan p = wgrad_plan(N, Cin, Cout, D, H, W, 0), q = wgrad_plan(N, Cin, Cout, D, H, W, 1);
+    return (size_t)(p.split > q.split ? p.split : q.split) * Cout * Cin * 27 * sizeof(float);
 }
 
 extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
@@ -1380,7 +1648,7 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     // running 32-bit offsets walk up to 128 channel planes past the last one: they must not wrap
     DRAM_REQUIRE(((int64_t)(a.Cin > Cout ? a.Cin : Cout) + 128) * (int64_t)D * H * W < 0x3fffffffLL,
                  "conv3d_k3_wgrad: (channels + 128) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
-    const WgradPlan p = wgrad_plan(N, a.Cin, Cout, D, H, W);
+    const WgradPlan p = wgrad_plan(N, a.Cin, Cout, D, H, W, x2 ? C1 : 0);
     const size_t need = (size_t)p.split * Cout * a.Cin * 27 * sizeof(float);
     if (ws_bytes < need) {
         set_error("conv3d_k3_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1392,7 +1660,10 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     // 16-byte staging needs full boxes along x and a channel tile that lies inside one source tensor
     const int ci_b = p.variant == 1 ? 16 : 32;
     const bool vec = (W % p.bx == 0) && (x2 == nullptr || C1 % ci_b == 0) && getenv("DRAM_WGRAD_NOVEC") == nullptr;
-    if (vec) {
+    if (p.wz) {
+        if (p.variant == 1) rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : launch_wgrad_wz<8, 4, 8, 1>(a, st);
+        else rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 4, 2>(a, st) : launch_wgrad_wz<8, 4, 4, 2>(a, st);
+    } else if (vec) {
         if (p.variant == 1) {
             if (p.bx == 32) rc = launch_wgrad_vec<32, 2, 1, 8, 1>(a, st);
             else if (p.bx == 16) rc = launch_wgrad_vec<16, 2, 2, 8, 1>(a, st);

@@ -77,9 +77,12 @@ def conv_fwd_kernel_name(dhw, Cout, Cin):
 def conv_wgrad_kernel_name(dhw, Cout, Cin=None):
     if Cin == 1:
         return "conv3d_k3_wgrad_c1_kernel"
+    tile = '8, 1' if Cout > 64 else '4, 2'
+    if dhw[2] % 8 == 0 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):   # csrc/conv3d_k3.hip wgrad_plan
+        return f"conv3d_k3_wgrad_wz_kernel<{'16, 2' if dhw[2] % 16 == 0 else '8, 4'}, {tile}>"
     box = _pick_box(dhw, [(16, 2, 2), (32, 2, 1), (8, 4, 2)])
     kind = "wgrad_vec" if dhw[2] % box[0] == 0 else "wgrad"       # 16-byte staging needs full boxes along x
-    return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {'8, 1' if Cout > 64 else '4, 2'}>"
+    return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {tile}>"
 
 
 def _p(t):
