@@ -934,33 +934,37 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a
 // slot from both (dY) / all four (X) planes and stores the transformed planes.
 template <int BX, int BY, int COS, int CIT>
 struct WgradWzGeom {
-    static constexpr int T = 512;
+    static constexpr int T = 64 * COS * CIT;            // 512: one block per CU; 256: two blocks per CU
     static constexpr int POS = BX * BY;                 // positions of the plane pair = K per box and xi
     static constexpr int RA = 4 * POS + 2;              // dY channel stride (4 planes): == 2 (mod 32) -> conflict-free A reads
     static constexpr int HY = BY + 2;
-    static constexpr int HXP = BX + 8;                  // padded halo row: [3 pad][left][BX interior][right][3 pad]
+    static constexpr int HXP = BX + 4;                  // halo row: [left][BX interior][right][2 pad]
     static constexpr int PLX = HY * HXP;                // one transformed X plane
     static constexpr int PB = PadTo2Mod32<4 * PLX>::value;
     static constexpr int CO_B = 16 * COS, CI_B = 16 * CIT;
     static constexpr int DY_TPC = POS / 4, DY_CPP = T / DY_TPC, DYP = (CO_B + DY_CPP - 1) / DY_CPP;
     static constexpr int XI_TPC = HY * (BX / 4), XI_CPP = T / XI_TPC, XIP = (CI_B + XI_CPP - 1) / XI_CPP;
     static constexpr int XE_TPC = HY * 2, XE_CPP = T / XE_TPC, XEP = (CI_B + XE_CPP - 1) / XE_CPP;
-    static constexpr size_t LDS_BYTES = (size_t)(CO_B * RA + CI_B * PB) * sizeof(float);
+    static constexpr int STAGE = CO_B * RA + CI_B * PB;  // floats of one (dY, X) tile pair
+    // two stages when they fit (one barrier per box, stores not serialised behind the slowest wave); otherwise
+    // (128 co tiles) a single stage with the stores between two barriers
+    static constexpr bool DOUBLE = 2 * (size_t)STAGE * sizeof(float) <= 160 * 1024;
+    static constexpr size_t LDS_BYTES = (DOUBLE ? 2 : 1) * (size_t)STAGE * sizeof(float);
 };
 
 template <int BX, int BY, int COS, int CIT>
-__global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a) {
+__global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a) {
     using G = WgradWzGeom<BX, BY, COS, CIT>;
-    constexpr int POS = G::POS, RA = G::RA, HXP = G::HXP, PLX = G::PLX, PB = G::PB;
+    constexpr int POS = G::POS, RA = G::RA, HXP = G::HXP, PLX = G::PLX, PB = G::PB, STAGE = G::STAGE;
     constexpr int CO_B = G::CO_B, CI_B = G::CI_B, DYP = G::DYP, XIP = G::XIP, XEP = G::XEP;
     constexpr int DY_TPC = G::DY_TPC, DY_CPP = G::DY_CPP, XI_TPC = G::XI_TPC, XI_CPP = G::XI_CPP, XE_TPC = G::XE_TPC, XE_CPP = G::XE_CPP;
-    static_assert(COS * CIT == 8 && BX % 4 == 0 && POS % 8 == 0 && PB % 2 == 0 && RA % 2 == 0 && DY_CPP >= 1 && XI_CPP >= 1 &&
-                      XE_CPP >= 1, "block geometry");
+    constexpr bool DOUBLE = G::DOUBLE;
+    static_assert((COS * CIT == 8 || COS * CIT == 4) && BX % 4 == 0 && POS % 8 == 0 && PB % 2 == 0 && RA % 2 == 0 && DY_CPP >= 1 &&
+                      XI_CPP >= 1 && XE_CPP >= 1, "block geometry");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldy = lds;             // [CO_B][4][POS] (+2)
-    float* lx = lds + CO_B * RA;  // [CI_B][4][HY][HXP]; halo x index h of a row at column h+3
+    // stage layout: dY [CO_B][4][POS] (+2), then X [CI_B][4][HY][HXP]; halo x index h of a row at column h
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1057,9 +1061,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a)
             }
         }
     };
-    auto store_box = [&]() {
-#pragma unroll
-        for (int p = 0; p < DYP; ++p)
+    // the staged registers go to LDS in NPIECE pieces (one pass of one slot kind each)
+    constexpr int NPIECE = DYP + XIP + XEP;
+    auto store_piece = [&](float* st, int piece) {
+        float* ldy = st;
+        float* lx = st + CO_B * RA;
+        if (piece < DYP) {
+            const int p = piece;
             if (d_act && (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B)) {
                 const f32x4 e0 = rdy[p][0], e1 = rdy[p][1];
                 const f32x4 pl[4] = {e0, e0 + e1, e0 - e1, -e1};
@@ -1070,32 +1078,39 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a)
                     *reinterpret_cast<f32x2*>(d + q * POS + 2) = f32x2{pl[q][2], pl[q][3]};
                 }
             }
-#pragma unroll
-        for (int p = 0; p < XIP; ++p)
+        } else if (piece < DYP + XIP) {
+            const int p = piece - DYP;
             if (i_act && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B)) {
                 const f32x4 d0 = rxi[p][0], d1 = rxi[p][1], d2 = rxi[p][2], d3 = rxi[p][3];
                 const f32x4 pl[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-                float* d = lx + (i_c + p * XI_CPP) * PB + i_r * HXP + 4 + 4 * i_j;       // 8-byte aligned
+                float* d = lx + (i_c + p * XI_CPP) * PB + i_r * HXP + 1 + 4 * i_j;       // interior starts at column 1
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    *reinterpret_cast<f32x2*>(d + q * PLX) = f32x2{pl[q][0], pl[q][1]};
-                    *reinterpret_cast<f32x2*>(d + q * PLX + 2) = f32x2{pl[q][2], pl[q][3]};
+                    d[q * PLX] = pl[q][0];
+                    d[q * PLX + 1] = pl[q][1];
+                    d[q * PLX + 2] = pl[q][2];
+                    d[q * PLX + 3] = pl[q][3];
                 }
             }
-#pragma unroll
-        for (int p = 0; p < XEP; ++p)
+        } else {
+            const int p = piece - DYP - XIP;
             if (e_act && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B)) {
                 const float d0 = rxe[p][0], d1 = rxe[p][1], d2 = rxe[p][2], d3 = rxe[p][3];
-                float* d = lx + (e_c + p * XE_CPP) * PB + e_r * HXP + (e_side ? BX + 4 : 3);
+                float* d = lx + (e_c + p * XE_CPP) * PB + e_r * HXP + (e_side ? BX + 1 : 0);
                 d[0] = d0 - d2;
                 d[PLX] = d1 + d2;
                 d[2 * PLX] = d2 - d1;
                 d[3 * PLX] = d1 - d3;
             }
+        }
     };
-    auto compute = [&]() {
-        const float* ap = ldy + (wco * 16 + i) * RA + k;
-        const float* bp = lx + (wci * 16 + i) * PB + k + 3;
+    auto store_box = [&](float* st) {
+#pragma unroll
+        for (int piece = 0; piece < NPIECE; ++piece) store_piece(st, piece);
+    };
+    auto compute = [&](const float* st) {
+        const float* ap = st + (wco * 16 + i) * RA + k;
+        const float* bp = st + CO_B * RA + (wci * 16 + i) * PB + k;
         constexpr int NU = POS;     // (POS/4 k-steps) x (4 planes)
         float av[2], bv[2][9];
         // one operand read of step u beside each MFMA of step u-1
@@ -1120,19 +1135,30 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a)
 
     if (sp < a.nboxes) {
         load_box(sp);
-        store_box();
+        store_box(lds);
     }
     __syncthreads();
+    int cur = 0;
     for (int box = sp; box < a.nboxes; box += a.split) {
         const bool has_next = (box + a.split) < a.nboxes;
         if (has_next) load_box(box + a.split);
         __builtin_amdgcn_sched_barrier(0);
-        compute();
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) {
+        if (DOUBLE) {
+            // a wave writes the next box into the idle stage as soon as ITS MFMAs are done -- while slower waves still
+            // compute -- and a box costs one barrier
+            compute(lds + cur * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) store_box(lds + (cur ^ 1) * STAGE);
             __syncthreads();
-            store_box();
-            __syncthreads();
+            cur ^= 1;
+        } else {
+            compute(lds);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                __syncthreads();
+                store_box(lds);
+                __syncthreads();
+            }
         }
     }
 
@@ -1439,7 +1465,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
     p.nbx = cdiv(W, p.bx); p.nby = cdiv(H, p.by); p.nbz = cdiv(D, p.bz);
     const int64_t nb = (int64_t)N * p.nbx * p.nby * p.nbz;
     p.nboxes = (int)nb;
-    p.ci_tiles = cdiv(Cin, p.variant == 1 ? 16 : 32);
+    p.ci_tiles = cdiv(Cin, p.variant == 0 ? 32 : 16);
     p.co_tiles = cdiv(Cout, p.variant == 1 ? 128 : 64);
     // Blocks = tiles x split, one 512-thread block resident per CU (256 at a time).  A last round
     // that is nearly empty costs a whole block duration (measured: 1032 blocks on 512 slots ran 1.5x
@@ -1496,7 +1522,7 @@ static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
         attr_done = true;
     }
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>), dim3(grid), dim3(G::T), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad(wz)");
 }
 
