@@ -412,6 +412,75 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
     for (int64_t e = i; e < n; e += stride) dx[e] = y[e] > 0.f ? dy[e] : 0.f;
 }
 
+// ---- cross-rank BatchNorm ("sbn"): the statistics / the backward sums leave the device between two stages ----
+// per channel: mean and M2 (sum of squared deviations) of the local rows, fp64 (Chan combine over rows x chunks)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nchunks, int64_t S, int N,
+                                                                int C, double* __restrict__ mean_m2) {
+    __shared__ double dred[4];
+    __shared__ double bc;
+    const int c = blockIdx.x;
+    const int64_t items = (int64_t)N * nchunks;
+    const double total = (double)N * (double)S;
+    double s = 0.0;
+    for (int64_t it = threadIdx.x; it < items; it += 256) {
+        const int64_t n = it / nchunks;
+        const int ch = (int)(it % nchunks);
+        s += (double)part[((size_t)(n * C + c) * nchunks + ch) * 2] * (double)chunk_len(S, ch);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = (dred[0] + dred[1] + dred[2] + dred[3]) / total;
+    __syncthreads();
+    const double mean = bc;
+    double m2 = 0.0;
+    for (int64_t it = threadIdx.x; it < items; it += 256) {
+        const int64_t n = it / nchunks;
+        const int ch = (int)(it % nchunks);
+        const float* o = part + ((size_t)(n * C + c) * nchunks + ch) * 2;
+        const double d = (double)o[0] - mean;
+        m2 += (double)o[1] + d * d * (double)chunk_len(S, ch);
+    }
+    m2 = wave_sum_d(m2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mean_m2[2 * c] = mean;
+        mean_m2[2 * c + 1] = dred[0] + dred[1] + dred[2] + dred[3];
+    }
+}
+
+// sums[2c] = sum_n s1[n,c], sums[2c+1] = sum_n s2[n,c]
+__global__ void bn_bwd_sums_kernel(const double* __restrict__ rowsum, double* __restrict__ sums, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        s1 += rowsum[2 * ((size_t)n * C + c)];
+        s2 += rowsum[2 * ((size_t)n * C + c) + 1];
+    }
+    sums[2 * c] = s1;
+    sums[2 * c + 1] = s2;
+}
+
+// per-row dx coefficients from (global) sums over `count` elements per channel
+__global__ void bn_pqr_from_sums_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                        const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                        float* __restrict__ pqr, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    const double rstd = save_rstd[c], mean = save_mean[c];
+    const double k1 = g * rstd;
+    const double k2 = -k1 * sums[2 * c + 1] / count, k3 = -k1 * sums[2 * c] / count;
+    const float p = (float)k1, q = (float)(k2 * rstd), r = (float)(k3 - k2 * rstd * mean);
+    for (int n = 0; n < N; ++n) {
+        float* o = pqr + 3 * ((size_t)n * C + c);
+        o[0] = p; o[1] = q; o[2] = r;
+    }
+}
+
 static inline bool vec_ok(const void* p, int64_t S) { return (S % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
 static int check_norm(const char* who, int kind, int G, int N, int C, int64_t S) {
@@ -533,6 +602,79 @@ extern "C" int dram_norm_bwd(const float* dy, const float* x, const float* gamma
     else
         hipLaunchKernelGGL(row_bwd_apply_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, pqr, dx, S, relu);
     return check_launch("norm_bwd");
+}
+
+extern "C" int dram_bn_stats(const float* x, double* mean_m2, int N, int C, int64_t S, void* ws, size_t ws_bytes,
+                             void* stream) {
+    DRAM_REQUIRE(x && mean_m2 && ws, "bn_stats: null pointer");
+    int rc = check_norm("bn_stats", DRAM_NORM_BATCH, 1, N, C, S);
+    if (rc) return rc;
+    DRAM_REQUIRE((int64_t)N * C <= 65535, "bn_stats: N*C > 65535 rows not supported");
+    if (ws_bytes < dram_norm_ws_bytes(N, C, S)) {
+        set_error("bn_stats: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(S);
+    const int64_t rows = (int64_t)N * C;
+    float* part = (float*)ws;
+    if (vec_ok(x, S)) hipLaunchKernelGGL(row_moments_kernel<true>, row_grid(nch, rows), dim3(256), 0, st, x, part, S, nch);
+    else hipLaunchKernelGGL(row_moments_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, x, part, S, nch);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, st, part, nch, S, N, C, mean_m2);
+    return check_launch("bn_stats");
+}
+
+extern "C" int dram_bn_bwd_sums(const float* dy, const float* x, const float* save_mean, const float* save_rstd,
+                                const float* rowcoef, double* sums, int relu, int N, int C, int64_t S, void* ws,
+                                size_t ws_bytes, void* stream) {
+    DRAM_REQUIRE(dy && x && save_mean && save_rstd && rowcoef && sums && ws, "bn_bwd_sums: null pointer");
+    int rc = check_norm("bn_bwd_sums", DRAM_NORM_BATCH, 1, N, C, S);
+    if (rc) return rc;
+    DRAM_REQUIRE((int64_t)N * C <= 65535, "bn_bwd_sums: N*C > 65535 rows not supported");
+    if (ws_bytes < dram_norm_ws_bytes(N, C, S)) {
+        set_error("bn_bwd_sums: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(S);
+    const int64_t rows = (int64_t)N * C;
+    float* part = (float*)ws;
+    double* rowsum = (double*)((char*)ws + align_up((size_t)rows * nch * 2 * sizeof(float), 256));
+    if (vec_ok(x, S) && vec_ok(dy, S))
+        hipLaunchKernelGGL(row_bwd_reduce_kernel<true>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, save_mean,
+                           save_rstd, part, S, nch, DRAM_NORM_BATCH, C, 1, relu);
+    else
+        hipLaunchKernelGGL(row_bwd_reduce_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, save_mean,
+                           save_rstd, part, S, nch, DRAM_NORM_BATCH, C, 1, relu);
+    hipLaunchKernelGGL(row_sum_chunks_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, st, part, rowsum, (int)rows, nch);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rowsum, sums, N, C);
+    return check_launch("bn_bwd_sums");
+}
+
+extern "C" int dram_bn_bwd_apply_sums(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                      const float* save_rstd, const float* rowcoef, const double* sums, double count,
+                                      float* dx, int relu, int N, int C, int64_t S, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    DRAM_REQUIRE(dy && x && save_mean && save_rstd && rowcoef && sums && dx && ws, "bn_bwd_apply_sums: null pointer");
+    int rc = check_norm("bn_bwd_apply_sums", DRAM_NORM_BATCH, 1, N, C, S);
+    if (rc) return rc;
+    DRAM_REQUIRE((int64_t)N * C <= 65535 && count > 0.0, "bn_bwd_apply_sums: bad dimensions");
+    if (ws_bytes < dram_norm_ws_bytes(N, C, S)) {
+        set_error("bn_bwd_apply_sums: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(S);
+    const int64_t rows = (int64_t)N * C;
+    float* pqr = (float*)((char*)ws + align_up((size_t)rows * nch * 2 * sizeof(float), 256) +
+                          align_up((size_t)rows * 2 * sizeof(double), 256));
+    hipLaunchKernelGGL(bn_pqr_from_sums_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, count, gamma, save_mean, save_rstd,
+                       pqr, N, C);
+    if (vec_ok(x, S) && vec_ok(dy, S) && vec_ok(dx, S))
+        hipLaunchKernelGGL(row_bwd_apply_kernel<true>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, pqr, dx, S, relu);
+    else
+        hipLaunchKernelGGL(row_bwd_apply_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, pqr, dx, S, relu);
+    return check_launch("bn_bwd_apply_sums");
 }
 
 extern "C" int dram_relu_fwd(const float* x, float* y, int64_t n, void* stream) {

@@ -30,6 +30,9 @@ SIGNATURES = {
     "dram_norm_fwd_train": (I, [P, P, P, P, P, P, P, P, P, F, F, I, I, I, I, I, L, P, Z, P]),
     "dram_bn_fwd_eval": (I, [P, P, P, P, P, P, P, P, P, F, I, I, I, L, P]),
     "dram_norm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, P, Z, P]),
+    "dram_bn_stats": (I, [P, P, I, I, L, P, Z, P]),
+    "dram_bn_bwd_sums": (I, [P, P, P, P, P, P, I, I, I, L, P, Z, P]),
+    "dram_bn_bwd_apply_sums": (I, [P, P, P, P, P, P, P, ctypes.c_double, P, I, I, I, L, P, Z, P]),
     "dram_relu_fwd": (I, [P, P, L, P]),
     "dram_relu_bwd": (I, [P, P, P, L, P]),
     "dram_maxpool3d_2_fwd": (I, [P, P, P, I, I, I, I, I, P]),

@@ -300,6 +300,84 @@ def norm_act(x, gamma, beta, running_mean, running_var, kind, groups, use_batch_
     return NormActFn.apply(x, gamma, beta, running_mean, running_var, kind, groups, use_batch_stats, momentum, eps, relu)
 
 
+class SyncBatchNormFn(Function):
+    """Training-mode BatchNorm whose statistics span all ranks of a process group (nn.SyncBatchNorm, the
+    reference's normal_wrapper "sbn", parts.py:32-33, under data parallelism).  Two exchanges per layer and
+    direction, 2*C doubles each: all-gather of {mean, M2, count} in forward (combined with Chan's formula in
+    fp64), all-reduce of {sum dy', sum dy'*xhat} in backward -- like torch's SyncBatchNorm, the parameter
+    gradients stay local sums and are averaged by the data-parallel gradient all-reduce."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group):
+        import torch.distributed as dist
+        x = _chk(x, "sync-bn input")
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        dev = x.device
+        st = _stream()
+        ws = _ws(_lib.lib.dram_norm_ws_bytes(N, C, S), dev)
+        local = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        call("dram_bn_stats", _p(x), _p(local), N, C, S, _p(ws), ws.numel(), st)
+        local[2 * C] = float(N * S)
+        world = dist.get_world_size(group)
+        allst = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(allst, local, group=group)
+        allst = torch.stack(allst)                                   # [world, 2C+1]
+        cnt = allst[:, 2 * C].view(world, 1)
+        means, m2s = allst[:, 0:2 * C:2], allst[:, 1:2 * C:2]
+        total = cnt.sum()
+        mean = (means * cnt).sum(0) / total
+        m2 = (m2s + cnt * (means - mean) ** 2).sum(0)                # Chan's parallel combine
+        var = m2 / total                                             # biased
+        mean_f, var_f = mean.float(), var.float()
+        if running_mean is not None:
+            with torch.no_grad():
+                unb = (m2 / (total - 1.0)).float() if float(total) > 1.0 else var_f
+                running_mean.mul_(1.0 - momentum).add_(mean_f, alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(unb, alpha=momentum)
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        rowcoef = torch.empty(2 * N * C, dtype=torch.float32, device=dev)
+        if gamma is not None:
+            gamma = _chk(gamma, "sync-bn weight", 1)
+        if beta is not None:
+            beta = _chk(beta, "sync-bn bias", 1)
+        call("dram_bn_fwd_eval", _p(x), _p(gamma), _p(beta), _p(mean_f), _p(var_f), _p(y), _p(save_mean), _p(save_rstd),
+             _p(rowcoef), float(eps), int(relu), N, C, S, st)
+        ctx.save_for_backward(x, gamma, save_mean, save_rstd, rowcoef)
+        ctx.cfg = (bool(relu), beta is not None, float(total), group)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, gamma, save_mean, save_rstd, rowcoef = ctx.saved_tensors
+        relu, has_beta, total, group = ctx.cfg
+        dy = _chk(dy, "sync-bn grad_output")
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        dev = x.device
+        st = _stream()
+        ws = _ws(_lib.lib.dram_norm_ws_bytes(N, C, S), dev)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        call("dram_bn_bwd_sums", _p(dy), _p(x), _p(save_mean), _p(save_rstd), _p(rowcoef), _p(sums), int(relu), N, C, S,
+             _p(ws), ws.numel(), st)
+        dbeta = sums[0::2].float() if has_beta else None
+        dgamma = sums[1::2].float() if gamma is not None else None
+        gsums = sums.clone()
+        dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
+        dx = torch.empty_like(x)
+        call("dram_bn_bwd_apply_sums", _p(dy), _p(x), _p(gamma), _p(save_mean), _p(save_rstd), _p(rowcoef), _p(gsums),
+             float(total), _p(dx), int(relu), N, C, S, _p(ws), ws.numel(), st)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def sync_batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, relu, group=None):
+    return SyncBatchNormFn.apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu, group)
+
+
 class ReLUFn(Function):
     @staticmethod
     def forward(ctx, x):

@@ -64,8 +64,30 @@ class HipBatchNorm3d(nn.BatchNorm3d, _NormMixin):
 
 
 class HipSyncBatchNorm(HipBatchNorm3d):
-    """"sbn" (parts.py:32-33).  Statistics are per process; cross-rank statistics need the
-    data-parallel wrapper (dram_amd.parallel), see DESIGN.md."""
+    """"sbn" (parts.py:32-33: nn.SyncBatchNorm).  In training mode with an initialised torch.distributed group of
+    more than one rank the batch statistics span all ranks (two small exchanges per layer and direction, see
+    functional.SyncBatchNormFn); otherwise -- like nn.SyncBatchNorm in the reference's single-process runs -- it is
+    plain BatchNorm.  `process_group` as in nn.SyncBatchNorm (None = the default group)."""
+
+    process_group = None
+
+    def forward(self, x, relu=False):
+        import torch.distributed as dist
+        sync = self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        if not sync:
+            return super().forward(x, relu)
+        self._check_input_dim(x)
+        eaf = 0.0 if self.momentum is None else self.momentum
+        if self.track_running_stats and self.num_batches_tracked is not None:
+            keep = 1.0
+            for _ in range(max(1, int(self.stat_updates))):
+                self.num_batches_tracked.add_(1)
+                m = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+                keep *= (1.0 - m)
+            eaf = 1.0 - keep
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return HF.sync_batch_norm(x, self.weight, self.bias, rm, rv, eaf, self.eps, relu, self.process_group)
 
 
 class HipGroupNorm(nn.GroupNorm, _NormMixin):

@@ -132,6 +132,22 @@ int dram_norm_bwd(const float* dy, const float* x, const float* gamma,
                   int kind, int G, int relu, int batch_stats, int N, int C, int64_t S,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---- cross-rank BatchNorm (normal_wrapper "sbn" = nn.SyncBatchNorm, dram/parts.py:32-33, under data parallelism) ----
+ * The statistics and the backward sums leave the device between two stages so that the host can exchange them
+ * (all-gather / all-reduce over RCCL); every stage is the same row kernels as above.
+ *   forward:  dram_bn_stats -> {mean, M2} per channel (fp64) of the local batch; combine over ranks on the host
+ *             side (Chan); then dram_bn_fwd_eval with the global mean / biased variance.
+ *   backward: dram_bn_bwd_sums -> {sum dy', sum dy'*xhat} per channel (= dbeta, dgamma of the local batch);
+ *             all-reduce; dram_bn_bwd_apply_sums with the global sums and element count.
+ * Workspace: dram_norm_ws_bytes(N, C, S). */
+int dram_bn_stats(const float* x, double* mean_m2, int N, int C, int64_t S, void* ws, size_t ws_bytes, void* stream);
+int dram_bn_bwd_sums(const float* dy, const float* x, const float* save_mean, const float* save_rstd,
+                     const float* rowcoef, double* sums, int relu, int N, int C, int64_t S, void* ws,
+                     size_t ws_bytes, void* stream);
+int dram_bn_bwd_apply_sums(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                           const float* save_rstd, const float* rowcoef, const double* sums, double count,
+                           float* dx, int relu, int N, int C, int64_t S, void* ws, size_t ws_bytes, void* stream);
+
 /* Stand-alone activations (act_wrapper parts.py:48-54 when no norm precedes them). */
 int dram_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int dram_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);

@@ -1,0 +1,73 @@
+"""Cross-rank BatchNorm ("sbn" under data parallelism): two processes share the GPU over gloo; each normalises its
+half of a batch with HipSyncBatchNorm and must reproduce -- output, input gradient, parameter gradients, running
+statistics -- what one process computes with HipBatchNorm3d on the whole batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _worker(rank, world, port, relu, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "bodyct-dram_amd")]
+    from dram_amd.modules import HipBatchNorm3d, HipSyncBatchNorm
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    N, C, shape = 6, 5, (4, 6, 8)
+    x = torch.randn((N, C) + shape, generator=g) * 2.0 + 3.0
+    gy = torch.randn((N, C) + shape, generator=g)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    lo, hi = (0, 2) if rank == 0 else (2, 6)            # uneven split: the combine must weight by count
+    m = HipSyncBatchNorm(C).cuda().train()
+    with torch.no_grad():
+        m.weight.copy_(w); m.bias.copy_(b)
+    xs = x[lo:hi].cuda().requires_grad_(True)
+    y = m(xs, relu=relu)
+    y.backward(gy[lo:hi].cuda())
+    # parameter gradients: local sums, summed over ranks = the whole-batch gradient
+    gw, gb = m.weight.grad.clone(), m.bias.grad.clone()
+    dist.all_reduce(gw); dist.all_reduce(gb)
+    ok = True
+    if rank == 0:
+        ref = HipBatchNorm3d(C).cuda().train()
+        with torch.no_grad():
+            ref.weight.copy_(w); ref.bias.copy_(b)
+        xr = x.cuda().requires_grad_(True)
+        yr = ref(xr, relu=relu)
+        yr.backward(gy.cuda())
+        close = lambda a, bb, tol=2e-5: ((a - bb).abs().max() <= tol * bb.abs().max().clamp_min(1e-6)).item()
+        ok = close(y, yr[lo:hi].detach()) and close(xs.grad, xr.grad[lo:hi]) and close(gw, ref.weight.grad) and \
+            close(gb, ref.bias.grad) and close(m.running_mean, ref.running_mean) and close(m.running_var, ref.running_var) \
+            and int(m.num_batches_tracked) == 1
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_sync_batchnorm_two_ranks_match_whole_batch(relu):
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = 29650 + int(relu)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, relu, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(0) is True and out.get(1) is True
+
+
+def test_sync_batchnorm_without_group_is_batchnorm():
+    from dram_amd.modules import HipBatchNorm3d, HipSyncBatchNorm
+    import parts
+    assert isinstance(parts.normal_wrapper("sbn", 4), HipSyncBatchNorm)
+    x = torch.randn(2, 4, 3, 5, 6, device="cuda")
+    a, b = HipSyncBatchNorm(4).cuda().train(), HipBatchNorm3d(4).cuda().train()
+    assert torch.equal(a(x), b(x))
