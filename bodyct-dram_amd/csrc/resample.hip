@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_vec_kernel(const float* __re
 struct Axis {
     int in, out;
     float scale;
+    int half;     // 0: align_corners=True (src = scale*dst); 1: align_corners=False (src = max(scale*(dst+0.5)-0.5, 0))
 };
 
 __device__ __forceinline__ void src_index(const Axis& a, int o, int& i0, int& i1, float& l0, float& l1) {
-    const float src = a.scale * (float)o;
+    const float src = a.half ? fmaxf(a.scale * ((float)o + 0.5f) - 0.5f, 0.f) : a.scale * (float)o;
     i0 = (int)src;
     if (i0 > a.in - 1) i0 = a.in - 1;
     i1 = i0 + (i0 < a.in - 1 ? 1 : 0);
@@ -136,8 +137,9 @@ __device__ __forceinline__ void touch_range(const Axis& a, int i, int& lo, int& 
     if (a.out <= 1 || a.scale <= 0.f) { lo = 0; hi = a.out - 1; return; }
     // conservative bounds from the inverse map, then clamp
     const float inv = 1.f / a.scale;
-    lo = (int)floorf((float)(i - 1) * inv) - 1;
-    hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    const float sh = a.half ? 0.5f : 0.f;
+    lo = (int)floorf(((float)(i - 1) + sh) * inv - sh) - 1;
+    hi = (int)ceilf(((float)(i + 1) + sh) * inv - sh) + 1;
     if (lo < 0) lo = 0;
     if (hi > a.out - 1) hi = a.out - 1;
 }
@@ -173,6 +175,7 @@ __device__ __forceinline__ Taps axis_taps(const Axis& a, int i) {
 }
 
 // host-side bound on the taps per input index, so that MAXT is never exceeded silently
+static int max_taps_host_scale(double s) { return s > 0.0 ? (int)(2.0 / s) + 3 : 1 << 20; }
 static int max_taps_host(int in, int out) {
     if (out <= 1 || in <= 1) return out;
     // outputs o with floor(o*s) in {i-1, i}: at most ceil(2/s)+1
@@ -315,11 +318,56 @@ __global__ __launch_bounds__(256) void crop_concat_bwd2_kernel(const float* __re
     dt2[plane * (int64_t)S2 + e] = v;
 }
 
+// ---------------------------------------------------------------- OneShot transforms
+// F.interpolate(mode='nearest'): src = min(floor(dst * scale), in-1), scale = in/out (ATen nearest_neighbor_compute_source_index)
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H,
+                                                             int W, int Do, int Ho, int Wo, float sz, float sy, float sx) {
+    const int64_t plane = blockIdx.y;
+    const int So = Do * Ho * Wo;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= So) return;
+    const int xo = e % Wo, yo = (e / Wo) % Ho, zo = e / (Wo * Ho);
+    const int zi = min((int)floorf((float)zo * sz), D - 1), yi = min((int)floorf((float)yo * sy), H - 1),
+              xi = min((int)floorf((float)xo * sx), W - 1);
+    y[plane * So + e] = x[plane * ((int64_t)D * H * W) + ((int64_t)zi * H + yi) * W + xi];
+}
+
+// torch.flip / torch.rot90 / transposes of the spatial axes: out[o0,o1,o2] = in[i], i[perm[k]] = flip[k] ? n-1-o[k] : o[k]
+struct PermFlip {
+    int od[3];      // output extents
+    int perm[3];    // output axis k reads input axis perm[k]
+    int flip[3];
+    int istride[3]; // element stride of input axis a
+};
+__global__ __launch_bounds__(256) void permute_flip_kernel(const float* __restrict__ x, float* __restrict__ y, PermFlip p) {
+    const int64_t plane = blockIdx.y;
+    const int So = p.od[0] * p.od[1] * p.od[2];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= So) return;
+    const int o2 = e % p.od[2], o1 = (e / p.od[2]) % p.od[1], o0 = e / (p.od[2] * p.od[1]);
+    const int o[3] = {o0, o1, o2};
+    int64_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) off += (int64_t)(p.flip[k] ? p.od[k] - 1 - o[k] : o[k]) * p.istride[p.perm[k]];
+    y[plane * So + e] = x[plane * So + off];
+}
+
 static inline Axis make_axis(int in, int out) {
     Axis a;
     a.in = in;
     a.out = out;
     a.scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    a.half = 0;
+    return a;
+}
+
+// align_corners=False: ATen area_pixel_compute_scale = in/out, or 1/scale_factor when the caller passed one
+static inline Axis make_axis_half(int in, int out, float given_scale) {
+    Axis a;
+    a.in = in;
+    a.out = out;
+    a.scale = given_scale > 0.f ? given_scale : (float)in / (float)out;
+    a.half = 1;
     return a;
 }
 
@@ -467,4 +515,71 @@ extern "C" int dram_crop_concat_bwd(const float* dout, float* dt1, float* dt2, i
                            oz, oy, ox);
     }
     return check_launch("crop_concat_bwd");
+}
+
+// ---- F.interpolate(mode='trilinear', align_corners=False) (Rescale3DOneShot on "#image" tensors,
+//      dram/data_transforms.py:1202-1239); scale_* > 0: the 1/scale_factor ATen uses when the caller gave scale factors
+extern "C" int dram_resize_trilinear_fwd(const float* x, float* y, int N, int C, int D, int H, int W, int Do, int Ho,
+                                         int Wo, float scale_z, float scale_y, float scale_x, void* stream) {
+    DRAM_REQUIRE(x && y, "resize_trilinear_fwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_trilinear_fwd: bad sizes");
+    int rc = check_planes("resize_trilinear_fwd", (int64_t)N * C, (int64_t)Do * Ho * Wo);
+    if (rc) return rc;
+    dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
+    hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis_half(D, Do, scale_z),
+                       make_axis_half(H, Ho, scale_y), make_axis_half(W, Wo, scale_x), N * C);
+    return check_launch("resize_trilinear_fwd");
+}
+
+extern "C" int dram_resize_trilinear_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, int Do, int Ho,
+                                         int Wo, float scale_z, float scale_y, float scale_x, void* stream) {
+    DRAM_REQUIRE(dy && dx, "resize_trilinear_bwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "resize_trilinear_bwd: bad sizes");
+    int rc = check_planes("resize_trilinear_bwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    const Axis az = make_axis_half(D, Do, scale_z), ay = make_axis_half(H, Ho, scale_y), ax = make_axis_half(W, Wo, scale_x);
+    if (max_taps_host_scale(az.scale) <= MAXT && max_taps_host_scale(ay.scale) <= MAXT && max_taps_host_scale(ax.scale) <= MAXT) {
+        dim3 grid(cdiv(D * H * W, 256), cdiv(N * C, TRI_CPT));
+        hipLaunchKernelGGL(trilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, az, ay, ax, N * C);
+    } else {
+        dim3 grid(cdiv(D * H * W, 256), N * C);
+        hipLaunchKernelGGL(trilinear_bwd_general_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dx, az, ay, ax);
+    }
+    return check_launch("resize_trilinear_bwd");
+}
+
+// ---- F.interpolate(mode='nearest') (Rescale3DOneShot on "#reference" tensors) ----
+extern "C" int dram_resize_nearest(const float* x, float* y, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                                   float scale_z, float scale_y, float scale_x, void* stream) {
+    DRAM_REQUIRE(x && y, "resize_nearest: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0 && (int64_t)N * C <= 65535, "resize_nearest: bad sizes");
+    int rc = check_planes("resize_nearest", (int64_t)N * C, (int64_t)Do * Ho * Wo);
+    if (rc) return rc;
+    const float sz = scale_z > 0.f ? scale_z : (float)D / (float)Do, sy = scale_y > 0.f ? scale_y : (float)H / (float)Ho,
+                sx = scale_x > 0.f ? scale_x : (float)W / (float)Wo;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(cdiv(Do * Ho * Wo, 256), N * C), dim3(256), 0, (hipStream_t)stream, x, y, D,
+                       H, W, Do, Ho, Wo, sz, sy, sx);
+    return check_launch("resize_nearest");
+}
+
+// ---- torch.flip / torch.rot90 over the spatial axes (Flip3DOneShot, Rotate903DOneShot, data_transforms.py:1140-1181):
+//      out[o] = in[i], i[perm[k]] = flip[k] ? n-1-o[k] : o[k]; (D,H,W) are the INPUT extents ----
+extern "C" int dram_spatial_permute_flip(const float* x, float* y, int N, int C, int D, int H, int W, const int* perm,
+                                         const int* flip, void* stream) {
+    DRAM_REQUIRE(x && y && perm && flip, "spatial_permute_flip: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && (int64_t)N * C <= 65535, "spatial_permute_flip: bad sizes");
+    int seen = 0;
+    for (int k = 0; k < 3; ++k) {
+        DRAM_REQUIRE(perm[k] >= 0 && perm[k] < 3, "spatial_permute_flip: perm must be a permutation of 0,1,2");
+        seen |= 1 << perm[k];
+    }
+    DRAM_REQUIRE(seen == 7, "spatial_permute_flip: perm must be a permutation of 0,1,2");
+    int rc = check_planes("spatial_permute_flip", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    const int id[3] = {D, H, W};
+    PermFlip p;
+    p.istride[0] = H * W; p.istride[1] = W; p.istride[2] = 1;
+    for (int k = 0; k < 3; ++k) { p.od[k] = id[perm[k]]; p.perm[k] = perm[k]; p.flip[k] = flip[k] ? 1 : 0; }
+    hipLaunchKernelGGL(permute_flip_kernel, dim3(cdiv(D * H * W, 256), N * C), dim3(256), 0, (hipStream_t)stream, x, y, p);
+    return check_launch("spatial_permute_flip");
 }

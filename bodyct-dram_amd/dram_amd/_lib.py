@@ -63,6 +63,10 @@ SIGNATURES = {
     "dram_prelu_bwd": (I, [P, P, P, P, P, P, Z, I, I, I, L, P]),
     "dram_global_max_fwd": (I, [P, P, P, I, L, P]),
     "dram_global_max_bwd": (I, [P, P, P, I, L, P]),
+    "dram_resize_trilinear_fwd": (I, [P, P, I, I, I, I, I, I, I, I, F, F, F, P]),
+    "dram_resize_trilinear_bwd": (I, [P, P, I, I, I, I, I, I, I, I, F, F, F, P]),
+    "dram_resize_nearest": (I, [P, P, I, I, I, I, I, I, I, I, F, F, F, P]),
+    "dram_spatial_permute_flip": (I, [P, P, I, I, I, I, I, P, P, P]),
     "dram_pcm_attention_fwd": (I, [P, P, P, I, I, I, P, I, I, I, I, I, P]),
     "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),

@@ -742,3 +742,119 @@ def pcm_attention(theta, phi, offsets, merge_type):
 
 def pcm_aggregate(attn, v, offsets):
     return PcmAggregateFn.apply(attn, v, tuple(map(tuple, offsets)))
+
+
+# --------------------------------------------------------------------------- OneShot transforms
+class ResizeTrilinearFn(Function):
+    """F.interpolate(x, size / scale_factor, mode='trilinear') with align_corners=False
+    (Rescale3DOneShot on "#image" tensors, reference data_transforms.py:1202-1239)."""
+
+    @staticmethod
+    def forward(ctx, x, size, scales):
+        x = _chk(x, "resize input", 5)
+        N, C, D, H, W = x.shape
+        Do, Ho, Wo = (int(v) for v in size)
+        y = torch.empty((N, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+        call("dram_resize_trilinear_fwd", _p(x), _p(y), N, C, D, H, W, Do, Ho, Wo, *scales, _stream())
+        ctx.geom = (N, C, D, H, W, Do, Ho, Wo, scales)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        N, C, D, H, W, Do, Ho, Wo, scales = ctx.geom
+        dy = _chk(dy, "resize grad_output", 5)
+        dx = torch.empty((N, C, D, H, W), dtype=torch.float32, device=dy.device)
+        call("dram_resize_trilinear_bwd", _p(dy), _p(dx), N, C, D, H, W, Do, Ho, Wo, *scales, _stream())
+        return dx, None, None
+
+
+def _resize_geometry(x, size, scale_factor):
+    """Output size and the per-axis source scale ATen uses (0 = the default in/out)."""
+    if (size is None) == (scale_factor is None):
+        raise ValueError("only one of size or scale_factor should be defined")
+    if size is not None:
+        size = tuple(int(v) for v in (size if isinstance(size, (tuple, list, torch.Size)) else (size,) * 3))
+        return size, (0.0, 0.0, 0.0)
+    sf = tuple(float(v) for v in (scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * 3))
+    size = tuple(int(math.floor(float(d) * s)) for d, s in zip(x.shape[2:], sf))
+    return size, tuple(1.0 / s for s in sf)      # recompute_scale_factor=None: the given factor maps coordinates
+
+
+def interpolate_trilinear(x, size=None, scale_factor=None):
+    size, scales = _resize_geometry(x, size, scale_factor)
+    return ResizeTrilinearFn.apply(x, size, scales)
+
+
+def interpolate_nearest(x, size=None, scale_factor=None):
+    """F.interpolate(mode='nearest'); label maps: no gradient."""
+    size, scales = _resize_geometry(x, size, scale_factor)
+    xc = _chk(x.detach(), "nearest input", 5)
+    N, C, D, H, W = xc.shape
+    y = torch.empty((N, C) + size, dtype=torch.float32, device=xc.device)
+    call("dram_resize_nearest", _p(xc), _p(y), N, C, D, H, W, *size, *scales, _stream())
+    return y
+
+
+class SpatialPermuteFlipFn(Function):
+    """A signed permutation of the spatial axes of [N,C,D,H,W] (torch.flip / torch.rot90 / transpose chains)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, flip):
+        x = _chk(x, "permute/flip input", 5)
+        N, C, D, H, W = x.shape
+        ind = (D, H, W)
+        y = torch.empty((N, C) + tuple(ind[p] for p in perm), dtype=torch.float32, device=x.device)
+        call("dram_spatial_permute_flip", _p(x), _p(y), N, C, D, H, W, (ctypes.c_int * 3)(*perm), (ctypes.c_int * 3)(*flip),
+             _stream())
+        ctx.pf = (perm, flip)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        perm, flip = ctx.pf
+        dy = _chk(dy, "permute/flip grad_output", 5)
+        inv_perm, inv_flip = [0, 0, 0], [0, 0, 0]
+        for k in range(3):                      # output axis k came from input axis perm[k] (flipped or not)
+            inv_perm[perm[k]], inv_flip[perm[k]] = k, flip[k]
+        N, C, D, H, W = dy.shape
+        ind = (D, H, W)
+        dx = torch.empty((N, C) + tuple(ind[p] for p in inv_perm), dtype=torch.float32, device=dy.device)
+        call("dram_spatial_permute_flip", _p(dy), _p(dx), N, C, D, H, W, (ctypes.c_int * 3)(*inv_perm),
+             (ctypes.c_int * 3)(*inv_flip), _stream())
+        return dx, None, None
+
+
+def signed_permutation(ops):
+    """Compose torch-style ops on the spatial axes into (perm, flip): ("flip", dims) and ("transpose", a, b)
+    with dims in 5-D numbering (2, 3, 4), applied in order."""
+    perm, flip = [0, 1, 2], [0, 0, 0]
+    for op in ops:
+        if op[0] == "flip":
+            for d in op[1]:
+                flip[d - 2] ^= 1
+        else:
+            a, b = op[1] - 2, op[2] - 2
+            perm[a], perm[b] = perm[b], perm[a]
+            flip[a], flip[b] = flip[b], flip[a]
+    return tuple(perm), tuple(flip)
+
+
+def rot90_ops(k, dims):
+    """torch.rot90(x, k, dims) as flips and a transpose."""
+    a, b = dims
+    k %= 4
+    if k == 0:
+        return []
+    if k == 1:
+        return [("flip", (b,)), ("transpose", a, b)]
+    if k == 2:
+        return [("flip", (a, b))]
+    return [("flip", (a,)), ("transpose", a, b)]
+
+
+def spatial_permute_flip(x, perm, flip):
+    if tuple(perm) == (0, 1, 2) and not any(flip):
+        return x
+    return SpatialPermuteFlipFn.apply(x, tuple(perm), tuple(flip))

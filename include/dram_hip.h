@@ -235,6 +235,23 @@ int dram_prelu_bwd(const float* dy, const float* x, const float* a, float* dx, f
 int dram_global_max_fwd(const float* x, float* out, int64_t* idx, int NC, int64_t S, void* stream);
 int dram_global_max_bwd(const float* dout, const int64_t* idx, float* dx, int NC, int64_t S, void* stream);
 
+/* ---- on-device OneShot transforms (dram/data_transforms.py:1140-1239, used by the affine-consistency
+ *      losses dram/metrics.py:213-310 on [N,C,D,H,W] device tensors) ----
+ * Rescale3DOneShot: F.interpolate(mode='trilinear') with align_corners=False on "#image" tensors (+ its adjoint, the
+ * probabilities are resized inside the loss) and mode='nearest' on "#reference" tensors.  scale_* <= 0: the default
+ * in/out; > 0: the 1/scale_factor ATen uses when the caller passed scale factors. */
+int dram_resize_trilinear_fwd(const float* x, float* y, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                              float scale_z, float scale_y, float scale_x, void* stream);
+int dram_resize_trilinear_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                              float scale_z, float scale_y, float scale_x, void* stream);
+int dram_resize_nearest(const float* x, float* y, int N, int C, int D, int H, int W, int Do, int Ho, int Wo,
+                        float scale_z, float scale_y, float scale_x, void* stream);
+/* Flip3DOneShot / Rotate903DOneShot (torch.flip, torch.rot90 over spatial axes): out[o] = in[i] with
+ * i[perm[k]] = flip[k] ? n-1-o[k] : o[k]; perm, flip: HOST arrays of 3 ints; (D,H,W) = input extents,
+ * output extents = (in[perm[0]], in[perm[1]], in[perm[2]]).  The adjoint is the inverse signed permutation. */
+int dram_spatial_permute_flip(const float* x, float* y, int N, int C, int D, int H, int W, const int* perm,
+                              const int* flip, void* stream);
+
 /* ---- IntRegRefineLoss, fused and device resident: dram/metrics.py:158-177 (interval hinge on
  *      the lobe-mean probability), 331-358 + 17-51 (pseudo label + BootBinCrossEntropy), 360-373 ----
  * dense, refined, lobes, lesions: [N,1,D,H,W] (S = D*H*W).  refined = the model's second output

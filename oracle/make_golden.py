@@ -269,6 +269,46 @@ def gen_misc(parts, models):
     _save("misc", **arrs)
 
 
+def gen_transforms():
+    """The OneShot tensor transforms (data_transforms.py:1140-1239) run by the reference on CPU tensors: every flip
+    subset, every rot90 axis pair x times, Rescale3DOneShot by size (up, down, mixed) and by factor, for "#image"
+    (trilinear, with the gradient of a random cotangent) and "#reference" (nearest) tensors."""
+    import data_transforms as DT
+    arrs = {}
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(2, 2, 5, 6, 7, generator=g)
+    lab = (torch.rand(2, 1, 5, 6, 7, generator=g) * 5).floor()
+    arrs["x"], arrs["lab"] = _np(x), _np(lab)
+    cases = []
+    for n in (1, 2, 3):
+        for axes in __import__("itertools").combinations((2, 3, 4), n):
+            cases.append(("flip", axes, None))
+    for axes in __import__("itertools").permutations((2, 3, 4), 2):
+        for k in (1, 2, 3):
+            cases.append(("rot", axes, k))
+    for i, (kind, axes, k) in enumerate(cases):
+        t = DT.Flip3DOneShot(flip_axis=axes) if kind == "flip" else DT.Rotate903DOneShot(rotate_axis=axes, rotate_times=k)
+        xi = x.clone().requires_grad_(True)
+        out = t({"#image": xi, "meta": 1})["#image"]
+        go = torch.randn(out.shape, generator=g)
+        (out * go).sum().backward()
+        arrs[f"pf/{i}/cfg"] = np.array([0 if kind == "flip" else 1, k or 0] + list(axes) + [0] * (3 - len(axes)))
+        arrs[f"pf/{i}/naxes"] = np.array(len(axes))
+        arrs[f"pf/{i}/out"], arrs[f"pf/{i}/gout"], arrs[f"pf/{i}/gin"] = _np(out), _np(go), _np(xi.grad)
+    rs = [("size", (8, 9, 11)), ("size", (3, 4, 5)), ("size", (7, 3, 12)), ("size", (5, 6, 7)), ("factor", (1.5, 0.75, 2.0)),
+          ("factor", (0.5, 0.5, 0.5))]
+    for i, (mode, sf) in enumerate(rs):
+        t = DT.Rescale3DOneShot(None, sf, mode=mode)
+        xi = x.clone().requires_grad_(True)
+        res = t({"#image": xi, "#reference": lab})
+        out, outl = res["#image"], res["#reference"]
+        go = torch.randn(out.shape, generator=g)
+        (out * go).sum().backward()
+        arrs[f"rs/{i}/mode"], arrs[f"rs/{i}/sf"] = np.array(0 if mode == "size" else 1), np.array(sf, dtype=np.float64)
+        arrs[f"rs/{i}/out"], arrs[f"rs/{i}/gout"], arrs[f"rs/{i}/gin"], arrs[f"rs/{i}/lab"] = _np(out), _np(go), _np(xi.grad), _np(outl)
+    _save("transforms", **arrs)
+
+
 SLIM_ATT = dict(SLIM, at_spatial_size=(6, 5, 7), at_f_dim=4, at_g_dim=3, at_g_iter=1, at_k_size=3,
                 at_merge_type="scaled_dot_product_relu", at_self_loop=False, at_layers=[-1, 0, 1],
                 at_p_enc_dim=0, at_geo_f_dim=0)
@@ -357,6 +397,8 @@ if __name__ == "__main__":
         gen_att(models)
     if not only or "misc" in only:
         gen_misc(parts, models)
+    if not only or "transforms" in only:
+        gen_transforms()
     if not only or "loss" in only:
         gen_loss()
     if not only or "loss2" in only:
