@@ -132,6 +132,41 @@ def test_conv3d_k3_linearity_and_shift_large():
     check(ya[:1, :, :8, :8, :8], ref0, "conv fwd corner vs oracle")
 
 
+@pytest.mark.parametrize("norm", ["ln", "in", "bn"])
+def test_config2_layer_full_size(norm):
+    """BASELINE config 2 at its full size: x = [4,64,128^3] ~ U[0,1) (2.1 GB), Conv3d(64,64,3,p=1) + norm + ReLU,
+    forward only -- reference layer us_modules.2.conv_blocks.1 (parts.py:140-146).  The conv is checked against
+    the oracle on an interior and a corner sub-volume (the full CPU conv takes minutes), the norm + ReLU of the
+    whole 2.1 GB conv output against the oracle's torch-CPU norm; tolerance 1e-4 (max-abs and rel-L2)."""
+    from dram_amd import functional as HF
+    import parts
+    N, C, S = 4, 64, 128
+    x = torch.rand(N, C, S, S, S, generator=g(2))
+    w = torch.randn(C, C, 3, 3, 3, generator=g(3)) * (2.0 / (C * 27)) ** 0.5       # kaiming normal, fan_in
+    xg, wg = dev(x), dev(w)
+    with torch.no_grad():
+        yc = HF.conv3d_k3(xg, wg)
+        sub = x[:1, :, 39:73, 59:85, 7:41].contiguous()
+        check(yc[:1, :, 40:72, 60:84, 8:40], O.conv3d(sub, w, None, 0), "config2 conv interior")
+        ref0 = O.conv3d(x[3:, :, S - 18:, :18, S - 18:].contiguous(), w, None, 1)[:, :, 2:, :16, 2:]
+        check(yc[3:, :, S - 16:, :16, S - 16:], ref0, "config2 conv corner")
+        m = parts.normal_wrapper(norm, C).to(DEV).train()
+        gmm, bta = torch.rand(C, generator=g(4)) + 0.5, torch.randn(C, generator=g(5)) * 0.2
+        m.weight.copy_(gmm); m.bias.copy_(bta)
+        out = m(yc, relu=True)
+        ycc = yc.cpu()
+        del yc
+        if norm == "bn":
+            ref = torch.nn.functional.batch_norm(ycc, None, None, gmm, bta, True, 0.1, O.EPS)
+        else:
+            ref = torch.nn.functional.group_norm(ycc, 1 if norm == "ln" else C, gmm, bta, O.EPS)
+        ref = torch.relu_(ref)
+        got = out.cpu()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        rel_l2 = ((got - ref).double().norm() / ref.double().norm()).item()
+        assert err <= 1e-4 and rel_l2 <= 1e-4, (norm, err, rel_l2)
+
+
 # ------------------------------------------------------------------ norms
 NORM_SHAPES = [(2, 6, 6, 10, 12), (3, 4, 7, 9, 11), (2, 8, 24, 24, 24)]   # 693-voxel rows exercise the scalar path
 
