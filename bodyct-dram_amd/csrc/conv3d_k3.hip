@@ -321,7 +321,7 @@ struct FwdWzGeom {
 
 template <int BX, int BY, int COT>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
-    static_assert(BX * BY == 128, "block covers 128 (y,x) positions of two z planes");
+    static_assert(BX * BY <= 128 && BX * BY > 96, "block covers (up to) 128 (y,x) positions of two z planes; lanes past BX*BY idle");
     using G = FwdWzGeom<BX, BY, COT>;
     constexpr int HX = G::HX, HP = G::HP, PK = G::PK, COB = G::COB;
     constexpr int WSLOTS = G::WSLOTS, WPASS = G::WPASS, IN_STAGE = G::IN_STAGE;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
     // ---- epilogue: A^T m per accumulator element, then the same stores as the direct kernel ----
     const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
     const int gx = x0 + vx, gy = y0 + vy;
-    if (gx < W && gy < H) {
+    if (pos < BX * BY && gx < W && gy < H) {
 #pragma unroll
         for (int zz = 0; zz < 2; ++zz) {
             const int gz = z0 + zz;
@@ -1420,12 +1420,24 @@ static bool use_wz(const ConvArgs& a) {
 
 static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     if (use_wz(a)) {
-        static const int boxes2[3][3] = {{32, 4, 1}, {16, 8, 1}, {8, 16, 1}};
+        // position boxes: the padded plane area, weighted by the lanes a box leaves idle (10x10 uses 100 of 128: the
+        // 20^3 and 10^3 levels of the reference's 80^3 chunks fit it exactly)
+        static const int boxes2[4][2] = {{32, 4}, {16, 8}, {8, 16}, {10, 10}};
         a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
-        switch (pick_box(1, a.H, a.W, boxes2, 3, "DRAM_FWD_BX")) {
+        int best = 0;
+        double best_cost = -1.0;
+        for (int i = 0; i < 4; ++i) {
+            const double cost = (double)cdiv(a.W, boxes2[i][0]) * cdiv(a.H, boxes2[i][1]) * 128.0;   // lane slots spent on a plane
+            if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        }
+        if (const char* f = getenv("DRAM_FWD_BX"))
+            for (int i = 0; i < 4; ++i)
+                if (atoi(f) == boxes2[i][0]) best = i;
+        switch (best) {
             case 0: return launch_fwd_wz<32, 4>(a, st);
             case 1: return launch_fwd_wz<16, 8>(a, st);
-            default: return launch_fwd_wz<8, 16>(a, st);
+            case 2: return launch_fwd_wz<8, 16>(a, st);
+            default: return launch_fwd_wz<10, 10>(a, st);
         }
     }
     static const int boxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
@@ -1449,10 +1461,10 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
     {   // Winograd-z: rows must be full boxes along x and a channel tile must lie inside one source tensor
         static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
         const int ci_b = p.variant == 1 ? 16 : 32;
-        const int bx = (W % 16 == 0) ? 16 : ((W % 8 == 0) ? 8 : 0);
+        const int bx = (W % 16 == 0) ? 16 : ((W % 8 == 0) ? 8 : ((W % 4 == 0) ? 4 : 0));
         if (!direct && bx && D >= 2 && (C1 == 0 || C1 % ci_b == 0)) {
             p.wz = 1;
-            p.bx = bx; p.by = bx == 16 ? 2 : 4; p.bz = 2;
+            p.bx = bx; p.by = 32 / bx; p.bz = 2;
         }
     }
     if (!p.wz) {
@@ -1687,8 +1699,10 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     const int ci_b = p.variant == 1 ? 16 : 32;
     const bool vec = (W % p.bx == 0) && (x2 == nullptr || C1 % ci_b == 0) && getenv("DRAM_WGRAD_NOVEC") == nullptr;
     if (p.wz) {
-        if (p.variant == 1) rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : launch_wgrad_wz<8, 4, 8, 1>(a, st);
-        else rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 4, 2>(a, st) : launch_wgrad_wz<8, 4, 4, 2>(a, st);
+        if (p.variant == 1)
+            rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : p.bx == 8 ? launch_wgrad_wz<8, 4, 8, 1>(a, st) : launch_wgrad_wz<4, 8, 8, 1>(a, st);
+        else
+            rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 4, 2>(a, st) : p.bx == 8 ? launch_wgrad_wz<8, 4, 4, 2>(a, st) : launch_wgrad_wz<4, 8, 4, 2>(a, st);
     } else if (vec) {
         if (p.variant == 1) {
             if (p.bx == 32) rc = launch_wgrad_vec<32, 2, 1, 8, 1>(a, st);
