@@ -1,16 +1,35 @@
-"""On-device OneShot transforms: the tensor transforms the reference's affine-consistency
-losses apply to [N,C,D,H,W] device tensors (dram/data_transforms.py:1140-1239, used by metrics.py:213-310), with the
-reference's class names, constructor arguments, random parameter choice and sample-dict protocol (keys containing
-"#" are transformed: "#image..." trilinear, "#reference..." nearest in Rescale3DOneShot).  torch.flip / torch.rot90 /
-F.interpolate are replaced by the gather kernels of csrc/resample.hip; all are differentiable where the reference's
-are (the loss resizes the predicted probabilities).  Rotate3DXOneShot (affine_grid + grid_sample, commented out of the
-reference's transform pool) is not provided."""
+"""On-device OneShot transforms.
+
+The reference's affine-consistency losses (dram/metrics.py:213-310) push [N,C,D,H,W] device tensors through
+`Flip3DOneShot`, `Rotate903DOneShot` and `Rescale3DOneShot` (dram/data_transforms.py:1140-1239): every dict entry
+whose key contains "#" is transformed, "#image..." entries with trilinear and "#reference..." entries with nearest
+interpolation when rescaling.  The classes here keep those names, constructor arguments, attributes
+(`flip_axis`, `rotate_axis`, `rotate_times`, `scale_factor`) and the way a random instance draws its parameters
+(same `random` / `numpy.random` calls in the same order), but run on the gather kernels of csrc/resample.hip instead
+of torch.flip / torch.rot90 / F.interpolate, and stay differentiable where the reference's are (the loss transforms the
+predicted probabilities).  `Rotate3DXOneShot` (affine_grid + grid_sample; commented out of the reference's transform
+pool) is not provided."""
+import itertools
 import random
-from itertools import combinations, permutations
 
 import numpy as np
 
 from . import functional as HF
+
+_SPATIAL_AXES = (2, 3, 4)
+
+
+class _OneShot:
+    """Sample-dict protocol shared by all transforms: tensors under keys with a '#' are transformed."""
+
+    def _transform(self, key, tensor):   # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def __call__(self, sample):
+        out = {}
+        for key, value in sample.items():
+            out[key] = self._transform(key, value) if "#" in key else value
+        return out
 
 
 class Identity:
@@ -21,74 +40,62 @@ class Identity:
         return sample
 
 
-class Flip3DOneShot:
-    """torch.flip over 1-3 randomly chosen axes of 2..4 (data_transforms.py:1140-1159)."""
+class Flip3DOneShot(_OneShot):
+    """Mirror along `flip_axis` (a tuple of axes out of 2, 3, 4).  Without an argument: 1-3 axes, drawn as the
+    reference does (one randint for the count, one sample from the combinations)."""
 
     def __init__(self, flip_axis=None, spatial_dim=2):
         self.spatial_dim = spatial_dim
         if flip_axis is None:
-            toss_int = random.randint(1, 3)
-            all_p = list(combinations([n for n in range(self.spatial_dim, 5)], toss_int))
-            flip_axis = random.sample(all_p, 1)[0]
+            count = random.randint(1, 3)
+            candidates = list(itertools.combinations(range(self.spatial_dim, 5), count))
+            flip_axis = random.sample(candidates, 1)[0]
         self.flip_axis = flip_axis
 
-    def _flip_axis(self, data):
-        assert data.dim() == 5
-        perm, flip = HF.signed_permutation([("flip", tuple(d % 5 for d in self.flip_axis))])
-        return HF.spatial_permute_flip(data, perm, flip)
-
-    def __call__(self, sample):
-        return {k: (self._flip_axis(v) if "#" in k else v) for k, v in sample.items()}
+    def _transform(self, key, tensor):
+        if tensor.dim() != 5:
+            raise AssertionError("Flip3DOneShot expects [N,C,D,H,W] tensors")
+        perm, flip = HF.signed_permutation([("flip", tuple(a % 5 for a in self.flip_axis))])
+        return HF.spatial_permute_flip(tensor, perm, flip)
 
 
-class Rotate903DOneShot:
-    """torch.rot90(rotate_times, rotate_axis) (data_transforms.py:1161-1181)."""
+class Rotate903DOneShot(_OneShot):
+    """`rotate_times` quarter turns in the plane `rotate_axis` = (a, b), torch.rot90 semantics.  Without arguments:
+    an ordered axis pair sampled from the 6 permutations, then 1-3 turns."""
 
     def __init__(self, rotate_axis=None, rotate_times=None, spatial_dim=2):
         self.spatial_dim = spatial_dim
         if rotate_axis is None:
-            all_p = list(permutations(list(range(self.spatial_dim, 5)), 2))
-            rotate_axis = random.sample(all_p, 1)[0]
+            pairs = list(itertools.permutations(range(self.spatial_dim, 5), 2))
+            rotate_axis = random.sample(pairs, 1)[0]
         self.rotate_axis = rotate_axis
-        self.rotate_times = random.randint(1, 3) if rotate_times is None else rotate_times
+        self.rotate_times = rotate_times if rotate_times is not None else random.randint(1, 3)
 
-    def _rotate_axis(self, data):
-        assert data.dim() == 5
-        perm, flip = HF.signed_permutation(HF.rot90_ops(self.rotate_times, tuple(d % 5 for d in self.rotate_axis)))
-        return HF.spatial_permute_flip(data, perm, flip)
-
-    def __call__(self, sample):
-        return {k: (self._rotate_axis(v) if "#" in k else v) for k, v in sample.items()}
+    def _transform(self, key, tensor):
+        if tensor.dim() != 5:
+            raise AssertionError("Rotate903DOneShot expects [N,C,D,H,W] tensors")
+        ops = HF.rot90_ops(self.rotate_times, tuple(a % 5 for a in self.rotate_axis))
+        return HF.spatial_permute_flip(tensor, *HF.signed_permutation(ops))
 
 
-class Rescale3DOneShot:
-    """F.interpolate to a size / by factors drawn from `rescale_factor_pool` (data_transforms.py:1202-1239)."""
+class Rescale3DOneShot(_OneShot):
+    """Resize to `scale_factor` read as a size (mode='size') or as per-axis factors (mode='factor'); without one,
+    three independent draws from `rescale_factor_pool`.  Images: trilinear (align_corners=False), label maps: nearest."""
 
     def __init__(self, rescale_factor_pool=None, scale_factor=None, mode='size'):
         self.rescale_factor_pool = rescale_factor_pool
         self.mode = mode
-        if scale_factor is None:
-            scale_factor = tuple(np.random.choice(self.rescale_factor_pool, 3))
-        self.scale_factor = scale_factor
+        self.scale_factor = tuple(np.random.choice(rescale_factor_pool, 3)) if scale_factor is None else scale_factor
 
-    def _rescale(self, data, mode):
-        fn = HF.interpolate_trilinear if mode == 'trilinear' else HF.interpolate_nearest
-        if self.mode == 'factor':
-            return fn(data, scale_factor=tuple(float(s) for s in self.scale_factor))
+    def _transform(self, key, tensor):
+        if "image" in key:
+            resize = HF.interpolate_trilinear
+        elif "reference" in key:
+            resize = HF.interpolate_nearest
+        else:
+            raise NotImplementedError(f"Rescale3DOneShot: do not know how to interpolate {key!r}")
         if self.mode == 'size':
-            return fn(data, size=tuple(int(s) for s in self.scale_factor))
-        return data
-
-    def __call__(self, sample):
-        new_sample = {}
-        for k, v in sample.items():
-            if "#" in k:
-                if "image" in k:
-                    mode = 'trilinear'
-                elif "reference" in k:
-                    mode = 'nearest'
-                else:
-                    raise NotImplementedError
-                v = self._rescale(v, mode)
-            new_sample[k] = v
-        return new_sample
+            return resize(tensor, size=tuple(int(v) for v in self.scale_factor))
+        if self.mode == 'factor':
+            return resize(tensor, scale_factor=tuple(float(v) for v in self.scale_factor))
+        return tensor       # the reference leaves the tensor untouched for any other mode
