@@ -55,6 +55,10 @@ CONV_CASES = [
     (1, 40, 72, 3, 5, 32, False),     # W a multiple of the box width: 16-byte staging path of wgrad (32-wide)
     (2, 24, 130, 4, 6, 16, False),    # ... 16-wide boxes, Cout > 128
     (1, 16, 16, 9, 6, 8, True),       # ... 8-wide boxes
+    (1, 8, 8, 1, 6, 8, False),        # D = 1: no plane pairs -> the direct kernels
+    (2, 12, 9, 2, 1, 4, True),        # a single plane pair, one row
+    (2, 16, 40, 5, 20, 20, False),    # 20^2 planes: 10x10-position forward boxes, 4x8 wgrad boxes, odd D
+    (1, 32, 64, 4, 10, 10, False),    # 10^2 planes (deepest level of an 80^3 chunk)
 ]
 
 
@@ -108,6 +112,19 @@ def test_conv3d_k3_virtual_concat(shape):
     # and the stand-alone crop_concat_5d kernel
     out = HF.crop_concat(dev(up), dev(skip))
     assert torch.equal(out.cpu(), O.crop_concat_5d(up, skip))
+
+
+def test_direct_conv_kernels_still_agree():
+    """DRAM_CONV_DIRECT=1 routes every layer to the direct (27-tap) kernels that the Winograd ones replaced by default;
+    they stay in the library as the A/B baseline and are kept verified by re-running the conv cases under that switch
+    (a child process: the switch is read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DRAM_CONV_DIRECT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_conv3d_k3_fwd_bwd or test_conv3d_k3_virtual_concat"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_conv3d_k3_linearity_and_shift_large():
