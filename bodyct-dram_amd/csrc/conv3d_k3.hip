@@ -4,23 +4,31 @@
 // nn.Conv3d modules of reference dram/parts.py:95,105,133,142,177,185.
 //
 // Design (MI355X): every 3x3x3 conv of DC3D with Cin >= 32 is FP32-FLOP bound
-// (200-2500 FLOP/B), so all three kernels are implicit GEMMs on the
+// (200-2500 FLOP/B), so all kernels are implicit GEMMs on the
 // exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32,
 // 157 TFLOP/s peak = the fp32 vector peak but one VGPR per operand and the VALU
 // left free).  Operand tiles are staged in LDS straight from NCDHW memory
 // (rows along x are contiguous -> coalesced), zero padding is materialised in
-// the LDS halo, and the 27 taps become compile-time LDS offsets.
+// the LDS halo, and the taps become compile-time LDS offsets.
+//
+// Two families (the library picks per layer, conv_fwd_dispatch / wgrad_plan):
+//   * Winograd F(2,3) along z -- conv3d_k3_fwd_wz_kernel (forward / backward-data) and
+//     conv3d_k3_wgrad_wz_kernel (backward-weights, the transposed algorithm): a pair of
+//     output planes costs 4 instead of 6 products per (ci, ky, kx) column, i.e. 2/3 of
+//     the MFMAs, with exact fp32 arithmetic.  Default for Cin >= 8 / W % 4 == 0.
+//   * direct 27-tap kernels -- conv3d_k3_fwd_kernel, conv3d_k3_wgrad(_vec)_kernel,
+//     conv3d_k3_wgrad_c1_kernel: the first layer (Cin = 1), widths the Winograd wgrad
+//     does not cover, and the A/B baseline (DRAM_CONV_DIRECT=1).
 //
 //   forward / backward-data  D[co][voxel] += W[co][ci] * X[ci][voxel+tap]
-//       block = 256 voxels (BX x BY x BZ box) x 32*COT output channels, 4 waves,
-//       each wave 2 voxel tiles x COT channel tiles of 32x32 (fp32 accumulators),
-//       K loop over channel chunks of 4 with all 27 taps unrolled.
+//       block = 256 voxels x 32*COT output channels, 4 waves of 32x32 accumulator
+//       tiles, K loop over channel chunks of 4 with all taps unrolled.
 //       The voxel index sits on the MFMA column (lane) axis so that every
 //       accumulator register is a 128-byte run along x of one output channel.
 //   backward-weights         dW[co][ci][tap] += dY[co][voxel] * X[ci][voxel+tap]
-//       block = 64 co x 16 ci x all 27 taps (27 independent 16x16 accumulators
-//       per wave), K loop over 128-voxel boxes, partial slabs + ordered reduce
-//       (deterministic, no float atomics).
+//       one 512-thread block per CU, each wave a 16x16 (co,ci) tile for all taps
+//       (27 / 36 independent accumulators), K loop over boxes of voxels, partial
+//       slabs + ordered reduce (deterministic, no float atomics).
 //
 // The input of forward and the output of backward-data may be a *virtual*
 // channel concatenation of two tensors (crop_concat_5d fused away).

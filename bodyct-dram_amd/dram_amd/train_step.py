@@ -4,11 +4,13 @@
 reference does not have: one process per GPU, gradients averaged with an RCCL
 all-reduce over xGMI.
 
-The loss math is a handful of element-wise passes over [N,1,D,H,W] tensors (<0.01 % of the
-step's FLOPs); it is written with torch ops on the device and -- unlike the reference, which
-round-trips every sample through numpy (metrics.py:338-352) -- never synchronises with the
-host.  The regression targets depend only on the data (lesion ratio, CT severity score), so they
-are computed when the batch is built, as the reference's data loader side would.
+The loss runs as two fused HIP kernels (csrc/loss.hip: one streaming pass for every sum of the
+regression hinge and the bootstrapped BCE, one for the gradient) and -- unlike the reference, which
+round-trips every sample through numpy (metrics.py:338-352) -- never synchronises with the host;
+`DeviceIntRegRefineLoss.reference_math` is the same loss spelled with torch ops, used by the CPU tests
+against the reference's golden vectors.  The regression targets depend only on the data (lesion
+ratio, CT severity score), so they are computed when the batch is built, as the reference's data
+loader side would.
 """
 import math
 
