@@ -309,6 +309,35 @@ def gen_transforms():
     _save("transforms", **arrs)
 
 
+API_NAMES = ("Identity", "normal_wrapper", "crop_concat_5d", "act_wrapper", "checkpoint_wrapper", "ConvBlock5d",
+             "UpsampleConvBlock5d", "ConvPoolBlock5d", "Initializer", "HeNorm", "pooling_dense_features", "DC3D", "PCM",
+             "DC3DATGeneric")
+# methods of the DGL message-passing formulation of PCM; the grid-stencil implementation has no counterpart
+PCM_DGL_INTERNALS = ("build_geo_feature", "merge_func", "compute_cross_x", "message_func", "reduce_func")
+
+
+def gen_signatures(parts, models):
+    """The call signatures (inspect.signature strings) of the reference's public callables of parts.py / models.py and
+    of their public methods: API facts the drop-in modules are checked against (tests/test_host_cpu.py)."""
+    import inspect
+    import json
+    out = {}
+    for mod in (parts, models):
+        for name in API_NAMES:
+            if not hasattr(mod, name):
+                continue
+            o = getattr(mod, name)
+            entry = {"module": mod.__name__, "signature": str(inspect.signature(o.__init__ if inspect.isclass(o) else o))}
+            if inspect.isclass(o):
+                entry["methods"] = {k: str(inspect.signature(v)) for k, v in vars(o).items()
+                                    if inspect.isfunction(v) and not k.startswith("__")}
+            out[name] = entry
+    path = os.path.join(OUT, "signatures.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path}")
+
+
 SLIM_ATT = dict(SLIM, at_spatial_size=(6, 5, 7), at_f_dim=4, at_g_dim=3, at_g_iter=1, at_k_size=3,
                 at_merge_type="scaled_dot_product_relu", at_self_loop=False, at_layers=[-1, 0, 1],
                 at_p_enc_dim=0, at_geo_f_dim=0)
@@ -399,6 +428,8 @@ if __name__ == "__main__":
         gen_misc(parts, models)
     if not only or "transforms" in only:
         gen_transforms()
+    if not only or "signatures" in only:
+        gen_signatures(parts, models)
     if not only or "loss" in only:
         gen_loss()
     if not only or "loss2" in only:

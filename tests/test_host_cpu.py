@@ -98,3 +98,27 @@ def test_dc3d_constructor_asserts():
     import models
     with pytest.raises(AssertionError):
         models.DC3D(1, [1, 2], [2, 2], [2], 1, [1, 1], [0, 0], 0.0)
+
+
+def test_public_signatures_match_reference(golden_dir):
+    """Every public callable of the reference's parts.py / models.py exists here with the same call signature, and so
+    does every public method (tests/golden/signatures.json, written by oracle/make_golden.py from the reference)."""
+    import inspect
+    import json
+    import models
+    import parts
+    from oracle.make_golden import PCM_DGL_INTERNALS
+    ref = json.load(open(os.path.join(golden_dir, "signatures.json")))
+    assert len(ref) == 14
+    for name, entry in ref.items():
+        mod = parts if entry["module"] == "parts" else models
+        obj = getattr(mod, name)
+        got = str(inspect.signature(obj.__init__ if inspect.isclass(obj) else obj))
+        assert got == entry["signature"], (name, got, entry["signature"])
+        for meth, sig in entry.get("methods", {}).items():
+            if name == "PCM" and meth in PCM_DGL_INTERNALS:
+                continue                                   # DGL message passing: replaced by the grid stencil kernels
+            assert hasattr(obj, meth), (name, meth)
+            if name == "PCM" and meth == "init_graph":
+                continue                                   # same name, returns the stencil offsets; arguments optional here
+            assert str(inspect.signature(getattr(obj, meth))) == sig, (name, meth)
