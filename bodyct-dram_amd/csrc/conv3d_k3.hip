@@ -1017,6 +1017,9 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
     const bool e_act = e_c < XE_CPP;
     const unsigned e_rel = (unsigned)(cs0 + e_c) * Ss4 + 4u * (unsigned)(e_r * Ws + (e_side ? BX : -1));
 
+    // NB every validity test below is folded into ONE select per load (non-short-circuit & on ints): a chain of &&
+    // makes hipcc split a load into two exec-masked loads of the same registers, with an s_waitcnt vmcnt(0) between
+    // them -- a full memory latency inside the issue sequence, per plane and pass
     auto load_box = [&](int box) {
         int bb = box;
         const int bx = bb % a.nbx; bb /= a.nbx;
@@ -1026,45 +1029,60 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
         const int x0 = bx * BX, y0 = by * BY, z0 = 2 * bz;
         {   // dY, planes z0 and z0+1 (full rows in x: W % BX == 0)
             const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(a.dy + (size_t)n * a.Cout * S), (unsigned)a.Cout * S4);
-            const bool ok = d_act && (y0 + d_vy) < H;
-            const bool ok1 = ok && (z0 + 1) < D;
-            unsigned run = 4u * (unsigned)((z0 * H + y0) * W + x0) + d_rel;
-            const unsigned inc = (unsigned)DY_CPP * S4;
+            const int ok = (int)d_act & (int)((y0 + d_vy) < H);
+            const int ok1 = ok & (int)((z0 + 1) < D);
+            const unsigned base = 4u * (unsigned)((z0 * H + y0) * W + x0) + d_rel;
+            unsigned run0 = ok ? base : OOB, run1 = ok1 ? base + zs4 : OOB;
+            const unsigned inc0 = ok ? (unsigned)DY_CPP * S4 : 0u, inc1 = ok1 ? (unsigned)DY_CPP * S4 : 0u;
 #pragma unroll
             for (int p = 0; p < DYP; ++p) {
-                const bool in = DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B;
-                rdy[p][0] = buf_load4(srd, (ok && in) ? run : OOB, 0);
-                rdy[p][1] = buf_load4(srd, (ok1 && in) ? run + zs4 : OOB, 0);
-                run += inc;
+                const int in = (DYP * DY_CPP == CO_B) | (int)(d_c + p * DY_CPP < CO_B);
+                rdy[p][0] = buf_load4(srd, in ? run0 : OOB, 0);
+                rdy[p][1] = buf_load4(srd, in ? run1 : OOB, 0);
+                run0 += inc0;
+                run1 += inc1;
             }
         }
         {   // X halo rows of the four planes z0-1 .. z0+2
             const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(xs + (size_t)n * Cs * Ss), (unsigned)Cs * Ss4);
             const unsigned origin = 4u * (unsigned)(((z0 - 1 + oz) * Hs + (y0 - 1 + oy)) * Ws + x0 + ox);   // may wrap: invalid rows are masked
             {
-                const bool okr = i_act && (unsigned)(y0 - 1 + i_r) < (unsigned)H;
-                unsigned run = origin + i_rel;
-                const unsigned inc = (unsigned)XI_CPP * Ss4;
+                const int okr = (int)i_act & (int)((unsigned)(y0 - 1 + i_r) < (unsigned)H);
+                unsigned run[4], inc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int okq = okr & (int)((unsigned)(z0 - 1 + q) < (unsigned)D);
+                    run[q] = okq ? origin + i_rel + (unsigned)q * zss4 : OOB;
+                    inc[q] = okq ? (unsigned)XI_CPP * Ss4 : 0u;
+                }
 #pragma unroll
                 for (int p = 0; p < XIP; ++p) {
-                    const bool in = okr && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B);
+                    const int in = (XIP * XI_CPP == CI_B) | (int)(i_c + p * XI_CPP < CI_B);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        rxi[p][q] = buf_load4(srd, (in && (unsigned)(z0 - 1 + q) < (unsigned)D) ? run + (unsigned)q * zss4 : OOB, 0);
-                    run += inc;
+                    for (int q = 0; q < 4; ++q) {
+                        rxi[p][q] = buf_load4(srd, in ? run[q] : OOB, 0);
+                        run[q] += inc[q];
+                    }
                 }
             }
             {
-                const bool okr = e_act && (unsigned)(y0 - 1 + e_r) < (unsigned)H && (e_side ? (x0 + BX) < W : x0 > 0);
-                unsigned run = origin + e_rel;
-                const unsigned inc = (unsigned)XE_CPP * Ss4;
+                const int okr = (int)e_act & (int)((unsigned)(y0 - 1 + e_r) < (unsigned)H) &
+                                (e_side ? (int)((x0 + BX) < W) : (int)(x0 > 0));
+                unsigned run[4], inc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int okq = okr & (int)((unsigned)(z0 - 1 + q) < (unsigned)D);
+                    run[q] = okq ? origin + e_rel + (unsigned)q * zss4 : OOB;
+                    inc[q] = okq ? (unsigned)XE_CPP * Ss4 : 0u;
+                }
 #pragma unroll
                 for (int p = 0; p < XEP; ++p) {
-                    const bool in = okr && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B);
+                    const int in = (XEP * XE_CPP == CI_B) | (int)(e_c + p * XE_CPP < CI_B);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        rxe[p][q] = buf_load(srd, (in && (unsigned)(z0 - 1 + q) < (unsigned)D) ? run + (unsigned)q * zss4 : OOB, 0);
-                    run += inc;
+                    for (int q = 0; q < 4; ++q) {
+                        rxe[p][q] = buf_load(srd, in ? run[q] : OOB, 0);
+                        run[q] += inc[q];
+                    }
                 }
             }
         }
