@@ -4,9 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With N > 1 and no WORLD_SIZE in the environment, `python bench.py --gpus N` starts the N ranks itself
+(fresh `torch.distributed.run` children, before this process touches the GPU) and exits with their status.
+
 A "step" is one optimisation step (forward + loss + backward + gradient all-reduce + Adam) of the
-reference's benchmark model `st_dram_ref.MODEL` (DC3D, BatchNorm, fp32, activation checkpointing as
-shipped) on this rank's batch of synthetic lobe chunks: 64 chunks of 1x128^3 per GPU (the shape
+reference's benchmark model `st_dram_ref.MODEL` (DC3D, BatchNorm, fp32; `checkpoint_layers` honoured in
+'stats' mode by default: no recomputation, the flagged blocks' double BatchNorm running-stat update is
+reproduced) on this rank's batch of synthetic lobe chunks: 64 chunks of 1x128^3 per GPU (the shape
 BASELINE.json's metric names), processed as gradient-accumulated micro-batches because 64x128^3 of
 saved activations does not fit 288 GB un-fused.  Inputs are resident in HBM before the
 timed region.  Weak scaling: the per-GPU batch is fixed.
@@ -31,6 +35,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 
 PEAK_HBM_GBS = 8000.0
 
 
+def wz_factor(kernel_name):
+    """Executed / algorithmic MFMA FLOPs of a conv kernel: 2/3 for the Winograd F(2,3)-along-z kernels."""
+    return 2.0 / 3.0 if "_wz_" in kernel_name else 1.0
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +52,7 @@ def parse():
     ap.add_argument("--checkpoint-mode", default="stats", choices=["stats", "recompute"],
                     help="how checkpoint_layers flags are honoured (models.DC3D.checkpoint_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to rehearse the multi-rank path with several ranks on one GPU)")
@@ -75,7 +84,10 @@ def host_cores():
 
 
 def cpu_baseline(budget_s):
-    """The oracle's torch-CPU DC3D (same config, same step shape at reduced batch) on the host cores."""
+    """The oracle's torch-CPU DC3D (same config, same kind of step: forward + backward, BatchNorm in training mode)
+    on this box's host cores, at the two reduced batches BASELINE.md section 3 names: 2 x 64^3 and 1 x 128^3.
+    `value` is the 1 x 128^3 figure (the metric's chunk shape); the 2 x 64^3 one rides along.  Bounded: one
+    warm-up + up to 3 reps at 64^3, then as many 128^3 reps (>= 1) as the rest of the budget allows."""
     import torch
     from oracle import dram_oracle as O
     threads = host_cores()
@@ -84,39 +96,68 @@ def cpu_baseline(budget_s):
     params, buffers = O.init_params(cfg, "bn", seed=0)
     for p in params.values():
         p.requires_grad_(True)
-    n, s = 1, 64
-    x = torch.rand(n, 1, s, s, s, generator=torch.Generator().manual_seed(1))
-    gout = torch.randn(n, 1, s, s, s, generator=torch.Generator().manual_seed(2))
 
-    def step():
-        for p in params.values():
-            p.grad = None
-        out = O.dc3d_forward(cfg, params, buffers, x, training=True, norm_method="bn")
-        (out * gout).sum().backward()
+    def measure(n, s, max_reps, budget, warm):
+        x = torch.rand(n, 1, s, s, s, generator=torch.Generator().manual_seed(1))
+        gout = torch.randn(n, 1, s, s, s, generator=torch.Generator().manual_seed(2))
+
+        def step():
+            for p in params.values():
+                p.grad = None
+            out = O.dc3d_forward(cfg, params, buffers, x, training=True, norm_method="bn")
+            (out * gout).sum().backward()
+
+        t_start = time.perf_counter()
+        if warm:
+            step()
+        times = []
+        while len(times) < max_reps:
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget:
+                break
+        times.sort()
+        return n * s ** 3 / times[len(times) // 2], len(times)
 
     t0 = time.perf_counter()
-    step()                                    # warm-up
-    first = time.perf_counter() - t0
-    times = []
-    while len(times) < 3 or (sum(times) + first < budget_s and len(times) < 10):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-        if sum(times) + first > budget_s and len(times) >= 1:
-            break
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": n * s ** 3 / med, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd, {n}x1x{s}^3, median of {len(times)} reps "
-                      f"after 1 warm-up, {threads} threads"}
+    v64, r64 = measure(2, 64, 3, 0.4 * budget_s, True)
+    left = max(1.0, budget_s - (time.perf_counter() - t0))
+    v128, r128 = measure(1, 128, 3, left, False)          # threads and primitives are warm from the 64^3 runs
+    return {"value": v128, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "value_2x64": v64,
+            "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd on {threads} threads: 1x1x128^3 median of {r128} "
+                      f"rep(s) (value); 2x1x64^3 median of {r64} reps after 1 warm-up (value_2x64)"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU,
+    `python -m torch.distributed.run`), before this process has imported torch or touched the GPU, and return
+    their exit status.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
     ensure_built()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks "
+                 f"(or run `python bench.py --gpus {args.gpus}`, which starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -135,7 +176,7 @@ def main():
     import models
     from dram_amd import functional as HF
     from dram_amd.train_step import DataParallelTrainer, synthetic_batch
-    from oracle.dram_oracle import ST_DRAM_REF_MODEL
+    from dram_amd.configs import ST_DRAM_REF_MODEL
 
     torch.manual_seed(0)                                   # same initial replica on every rank
     model = models.DC3D(**ST_DRAM_REF_MODEL, norm_method=args.norm)
@@ -175,32 +216,42 @@ def main():
     # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region
     roofline = None
     kernels = {}
+    summ = {}
     if rank == 0 and use_timer:
         summ = timer.summary()
         for k, d in summ.items():
+            ex = d["flops"] * wz_factor(k)
             kernels[k] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"], "total_ms": d["ms"],
-                          "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
+                          "executed_tflops": ex / (d["ms"] * 1e-3) / 1e12,
+                          "algorithmic_equiv_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12}
         if summ:
             dom = max(summ, key=lambda k: summ[k]["ms"])
             d = summ[dom]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            # "achieved" counts the ALGORITHMIC work of SURVEY section 8(d): 54*Cin*Cout FLOP per voxel, the
-            # direct 27-tap convolution.  The *_wz_* kernels run Winograd F(2,3) along z, i.e. they execute 2/3 of
-            # those multiply-adds on the fp32 matrix cores (exact fp32 arithmetic): their algorithmic rate can
-            # exceed the MFMA peak, and "executed" prices what was really issued against that peak.
-            executed = ach * (2.0 / 3.0 if "_wz_" in dom else 1.0)
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                        "executed": {"tflops": executed, "frac": executed / PEAK_FP32_MFMA_TFLOPS,
-                                     "note": "MFMA FLOPs actually issued (Winograd F(2,3) along z: 36 instead of 54 "
-                                             "multiply-adds per input/output channel pair and voxel)"
-                                     if "_wz_" in dom else "direct algorithm: executed == algorithmic"},
+            # SURVEY section 8(d) counts the ALGORITHMIC work of a 3x3x3 conv as the direct 27-tap form,
+            # 54*Cin*Cout FLOP per voxel.  The *_wz_* kernels run Winograd F(2,3) along z: they EXECUTE 2/3 of those
+            # multiply-adds on the fp32 matrix cores (exact fp32).  The roofline fraction prices what was really
+            # issued against the MFMA peak (always <= 1); the direct-equivalent rate is reported beside it.
+            alg = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            ex = alg * wz_factor(dom)
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": ex, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ex / PEAK_FP32_MFMA_TFLOPS,
+                        "executed_tflops": ex, "algorithmic_equiv_tflops": alg,
+                        "executed_flops_per_launch": d["flops"] * wz_factor(dom) / d["launches"],
+                        "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+                        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                         "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
-                        "algorithmic_flops_per_launch": d["flops"] / d["launches"], "traffic": None}
+                        "traffic": None, "traffic_bytes_per_launch": None,
+                        "note": "achieved/frac = MFMA FLOPs actually issued (Winograd F(2,3) along z: 36 instead of 54 "
+                                "multiply-adds per channel pair and voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = "
+                                "direct-conv FLOPs of SURVEY 8(d) / time"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
             if os.path.exists(pmc):
                 try:
-                    roofline["traffic"] = json.load(open(pmc)).get(dom)
+                    t = json.load(open(pmc)).get(dom)
+                    if t:
+                        roofline["traffic"] = roofline["traffic_bytes_per_launch"] = t["total_bytes"]
+                        roofline["traffic_read_bytes_per_launch"] = t["read_bytes"]
+                        roofline["traffic_write_bytes_per_launch"] = t["write_bytes"]
                 except Exception:
                     pass
     if world > 1:
@@ -212,6 +263,9 @@ def main():
 
     if rank == 0:
         flops_per_voxel = 5415936.0     # fwd+bwd algorithmic FLOPs per input voxel
+        tot_alg = sum(d["flops"] for d in summ.values())
+        tot_ex = sum(d["flops"] * wz_factor(k) for k, d in summ.items())
+        exec_ratio = tot_ex / tot_alg if tot_alg else (2.0 / 3.0)
         line = {
             "metric": "voxels/sec fwd+bwd (DC3D train step) on 64x128^3 CT chunks per GPU",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -224,7 +278,10 @@ def main():
                        "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,
                        "parallelism": f"dp{world}"},
             "per_gpu_voxels_per_s": value / world,
-            "network_frac_of_fp32_peak": value / world * flops_per_voxel / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 where the
+            # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
+            "network_executed_frac_of_fp32_peak": value / world * flops_per_voxel * exec_ratio / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "network_algorithmic_equiv_tflops": value / world * flops_per_voxel / 1e12,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)

@@ -27,6 +27,26 @@ inline int check_launch(const char* what) {
         }                                  \
     } while (0)
 
+// Opt-in to more than 64 KB of dynamic LDS for a kernel.  The attribute belongs to the (function, device)
+// pair, so the "already done" flag is kept per device of the calling thread (a process that drives several
+// devices sets it once on each); racing threads at worst set it twice.
+constexpr int DRAM_MAX_DEVICES = 64;
+struct LdsAttrOnce {
+    unsigned char done[DRAM_MAX_DEVICES] = {};
+};
+inline int ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttrOnce& once, const char* who) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DRAM_MAX_DEVICES) dev = -1;
+    if (dev >= 0 && once.done[dev]) return DRAM_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed: %s", who, bytes, hipGetErrorString(e));
+        return DRAM_EHIP;
+    }
+    if (dev >= 0) once.done[dev] = 1;
+    return DRAM_OK;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1348,16 +1348,8 @@ __global__ void pack_weights_wz_kernel(const float* __restrict__ w, float* __res
 template <int BX, int BY, int COT>
 static int launch_fwd_wz_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
     using G = FwdWzGeom<BX, BY, COT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_fwd_wz_kernel<BX, BY, COT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("conv3d_k3_fwd(wz): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return DRAM_EHIP;
-        }
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wz_kernel<BX, BY, COT>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd(wz)")) return rc;
     a.co_tiles = cdiv(a.Cout, 32 * COT);
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
@@ -1386,16 +1378,8 @@ static int launch_fwd_wz(ConvArgs& a, hipStream_t st) {
 template <int BX, int BY, int BZ, int COT>
 static int launch_fwd_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
     using G = FwdGeom<BX, BY, BZ, COT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_fwd_kernel<BX, BY, BZ, COT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("conv3d_k3_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return DRAM_EHIP;
-        }
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_kernel<BX, BY, BZ, COT>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd")) return rc;
     a.co_tiles = cdiv(a.Cout, 32 * COT);
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
@@ -1531,16 +1515,8 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
 template <int BX, int BY, int BZ, int COS, int CIT>
 static int launch_wgrad_vec(WgradArgs& a, hipStream_t st) {
     using G = WgradVecGeom<BX, BY, BZ, COS, CIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return DRAM_EHIP;
-        }
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     hipLaunchKernelGGL((conv3d_k3_wgrad_vec_kernel<BX, BY, BZ, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad(vec)");
@@ -1549,16 +1525,8 @@ static int launch_wgrad_vec(WgradArgs& a, hipStream_t st) {
 template <int BX, int BY, int COS, int CIT>
 static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
     using G = WgradWzGeom<BX, BY, COS, CIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return DRAM_EHIP;
-        }
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>), dim3(grid), dim3(G::T), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad(wz)");
@@ -1567,16 +1535,8 @@ static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
 template <int BX, int BY, int BZ, int COS, int CIT>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
     using G = WgradGeom<BX, BY, BZ, COS, CIT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ, COS, CIT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("conv3d_k3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return DRAM_EHIP;
-        }
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_kernel<BX, BY, BZ, COS, CIT>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<BX, BY, BZ, COS, CIT>), dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad");

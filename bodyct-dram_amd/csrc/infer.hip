@@ -27,26 +27,46 @@ __global__ void bbox_init_kernel(int* boxes, int nlabels) {
 
 __global__ __launch_bounds__(256) void label_bboxes_kernel(const uint8_t* __restrict__ lobe, int* __restrict__ boxes,
                                                            int nlabels, int D, int H, int W) {
-    // one block per (z, y-strip); per-wave reduction of x extents, then integer atomics (deterministic)
+    // One block per row (z, y), ONE pass over the row for every label 1..nlabels (evaluate_scan visits every
+    // value of np.unique(lobe)[1:], job_runner.py:729, not just 1..5): a wave peels the distinct labels among
+    // its 64 voxels (usually one or two), reduces their x extent with shuffles and merges it into the row's
+    // per-label extents in LDS; then one integer atomic set per label present in the row (deterministic).
+    __shared__ int lmin[256], lmax[256];
+    lmin[threadIdx.x] = 0x7fffffff;
+    lmax[threadIdx.x] = -1;
+    __syncthreads();
     const int z = blockIdx.y;
     const int y = blockIdx.x;
     const uint8_t* row = lobe + ((size_t)z * H + y) * W;
-    for (int l = 1; l <= nlabels; ++l) {
-        int xmin = 0x7fffffff, xmax = -1;
-        for (int x = threadIdx.x; x < W; x += 256) {
-            if (row[x] == l) { xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; }
-        }
+    const int lane = threadIdx.x & 63;
+    for (int xb = 0; xb < W; xb += 256) {
+        const int x = xb + threadIdx.x;
+        const int v = x < W ? (int)row[x] : 0;
+        unsigned long long pending = __ballot(v != 0 && v <= nlabels);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int lab = __shfl(v, leader, 64);
+            const bool mine = v == lab;
+            int xmin = mine ? x : 0x7fffffff, xmax = mine ? x : -1;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int a = __shfl_xor(xmin, o, 64), b = __shfl_xor(xmax, o, 64);
-            xmin = a < xmin ? a : xmin;
-            xmax = b > xmax ? b : xmax;
+            for (int o = 32; o > 0; o >>= 1) {
+                const int a = __shfl_xor(xmin, o, 64), b = __shfl_xor(xmax, o, 64);
+                xmin = a < xmin ? a : xmin;
+                xmax = b > xmax ? b : xmax;
+            }
+            if (lane == leader) {
+                atomicMin(&lmin[lab], xmin);
+                atomicMax(&lmax[lab], xmax);
+            }
+            pending &= ~__ballot(mine);
         }
-        if ((threadIdx.x & 63) == 0 && xmax >= 0) {
-            int* bx = boxes + (l - 1) * 6;
-            atomicMin(bx + 0, z); atomicMin(bx + 1, y); atomicMin(bx + 2, xmin);
-            atomicMax(bx + 3, z); atomicMax(bx + 4, y); atomicMax(bx + 5, xmax);
-        }
+    }
+    __syncthreads();
+    const int l = threadIdx.x;
+    if (l >= 1 && l <= nlabels && lmax[l] >= 0) {
+        int* bx = boxes + (l - 1) * 6;
+        atomicMin(bx + 0, z); atomicMin(bx + 1, y); atomicMin(bx + 2, lmin[l]);
+        atomicMax(bx + 3, z); atomicMax(bx + 4, y); atomicMax(bx + 5, lmax[l]);
     }
 }
 

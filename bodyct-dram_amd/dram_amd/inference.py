@@ -7,8 +7,8 @@ resample to RESAMPLE_SIZE (80^3), run the model, sigmoid, resize back to the cro
 where the lobe is; then the thresholding of `LesionSegTest.run` (job_runner.py:1003-1005):
 Otsu on the 8-bit heat map inside the lungs (`binary_cam`, dram/utils.py:226-242), mask = htp > th.
 
-Differences from the reference, on purpose: the <= 5 lobes go through the model as ONE batch of
-N = #lobes chunks; the scan and the label map are uploaded once and every step runs on the device
+Differences from the reference, on purpose: the lobes (every non-zero label of the map, like
+`np.unique(lobe)[1:]`; normally 5) go through the model in batches of up to 8 chunks; the scan and the label map are uploaded once and every step runs on the device
 (the reference round-trips each lobe through numpy and SimpleITK); the crop -> 80^3 resampling is
 trilinear with align_corners=True (SimpleITK is not available here: that step's parity is unpinned;
 the way back uses the same operator as the reference's F.interpolate(align_corners=True)).
@@ -56,10 +56,16 @@ def binary_cam_threshold(hist, scaler=1.0):
 
 
 class LobeInference:
-    """model: a models.DC3D on the GPU.  run(scan_i16, lobe_u8, spacing) -> dict."""
+    """model: a models.DC3D on the GPU.  run(scan_i16, lobe_u8, spacing) -> dict.  Every label 1..max_labels
+    present in the uint8 lobe map is visited in ascending order (evaluate_scan: `np.unique(lobe)[1:]`,
+    job_runner.py:729); a label above max_labels raises instead of being silently left out of the heat map."""
 
-    def __init__(self, model, resample_size=80, window=(-1000.0, -300.0), border_mm=5.0, max_labels=5):
-        self.model, self.R, self.window, self.border, self.max_labels = model, int(resample_size), window, border_mm, max_labels
+    MAX_CHUNKS = 8     # chunks per kernel call / model batch (csrc/infer.hip MAX_CHUNKS)
+
+    def __init__(self, model, resample_size=80, window=(-1000.0, -300.0), border_mm=5.0, max_labels=255):
+        if not 1 <= int(max_labels) <= 255:
+            raise ValueError("max_labels must be in 1..255 (uint8 label map)")
+        self.model, self.R, self.window, self.border, self.max_labels = model, int(resample_size), window, border_mm, int(max_labels)
 
     @torch.no_grad()
     def run(self, scan, lobe, spacing):
@@ -72,7 +78,11 @@ class LobeInference:
         st = torch.cuda.current_stream().cuda_stream
         boxes = torch.empty(self.max_labels * 6, dtype=torch.int32, device=dev)
         call("dram_label_bboxes", lobe.data_ptr(), boxes.data_ptr(), self.max_labels, D, H, W, st)
-        boxes = boxes.cpu().numpy().reshape(self.max_labels, 6)            # the only sync before the model: 30 ints
+        top = int(lobe.max()) if self.max_labels < 255 else 0             # (a second small sync only when labels are capped)
+        if top > self.max_labels:
+            raise ValueError(f"lobe map holds label {top} > max_labels={self.max_labels}: it would be left out of the "
+                             f"heat map while still counting in the lesion ratio")
+        boxes = boxes.cpu().numpy().reshape(self.max_labels, 6)            # the only sync before the model: 6 ints per label
         chunks = []
         for label in range(1, self.max_labels + 1):
             lo, hi = boxes[label - 1, :3], boxes[label - 1, 3:]
@@ -88,16 +98,22 @@ class LobeInference:
         if not chunks:
             return {"htp": htp, "mask": torch.zeros((D, H, W), dtype=torch.uint8, device=dev), "threshold": 0.0,
                     "lesion_ratio": 0.0, "ctss": 0, "chunks": []}
-        L, R = len(chunks), self.R
-        carr = (ctypes.c_int * (7 * L))(*[v for c in chunks for v in c])
-        x = torch.empty((L, 1, R, R, R), dtype=torch.float32, device=dev)
-        call("dram_lobe_chunks", scan.data_ptr(), lobe.data_ptr(), x.data_ptr(), carr, L, D, H, W, R,
-             float(self.window[0]), float(self.window[1]), st)
+        R = self.R
+        x = torch.empty((len(chunks), 1, R, R, R), dtype=torch.float32, device=dev)
         was_training = self.model.training
         self.model.eval()
-        _, dense = self.model(x, None)       # one batch of L lobe chunks; the 2nd output is used (job_runner.py:764)
-        self.model.train(was_training)
-        call("dram_lobe_paste", dense.contiguous().data_ptr(), lobe.data_ptr(), htp.data_ptr(), carr, L, D, H, W, R, st)
+        try:
+            for g0 in range(0, len(chunks), self.MAX_CHUNKS):
+                grp = chunks[g0:g0 + self.MAX_CHUNKS]
+                L = len(grp)
+                carr = (ctypes.c_int * (7 * L))(*[v for c in grp for v in c])
+                xg = x[g0:g0 + L]
+                call("dram_lobe_chunks", scan.data_ptr(), lobe.data_ptr(), xg.data_ptr(), carr, L, D, H, W, R,
+                     float(self.window[0]), float(self.window[1]), st)
+                _, dense = self.model(xg, None)   # one batch of L lobe chunks; the 2nd output is used (job_runner.py:764)
+                call("dram_lobe_paste", dense.contiguous().data_ptr(), lobe.data_ptr(), htp.data_ptr(), carr, L, D, H, W, R, st)
+        finally:
+            self.model.train(was_training)
         hist = torch.empty(256, dtype=torch.int64, device=dev)
         ssum = torch.empty(1, dtype=torch.float64, device=dev)
         call("dram_lung_hist256", htp.data_ptr(), lobe.data_ptr(), hist.data_ptr(), ssum.data_ptr(), htp.numel(), st)

@@ -6,9 +6,9 @@ all-reduce over xGMI.
 
 The loss runs as two fused HIP kernels (csrc/loss.hip: one streaming pass for every sum of the
 regression hinge and the bootstrapped BCE, one for the gradient) and -- unlike the reference, which
-round-trips every sample through numpy (metrics.py:338-352) -- never synchronises with the host;
-`DeviceIntRegRefineLoss.reference_math` is the same loss spelled with torch ops, used by the CPU tests
-against the reference's golden vectors.  The regression targets depend only on the data (lesion
+round-trips every sample through numpy (metrics.py:338-352) -- never synchronises with the host
+(`oracle.dram_oracle.fused_loss_math` spells the same fused formulation with torch ops for the CPU tests
+against the reference's golden vectors).  The regression targets depend only on the data (lesion
 ratio, CT severity score), so they are computed when the batch is built, as the reference's data
 loader side would.
 """
@@ -92,51 +92,26 @@ class DeviceIntRegRefineLoss:
         self.band_width, self.smoothing, self.eps = band_width, smoothing, 1e-7
 
     def __call__(self, dense, batch, refined=None):
-        """`refined`: the model's second output when it differs from `dense` (DC3DATGeneric)."""
-        if dense.is_cuda:   # the product path: two fused HIP kernels (csrc/loss.hip)
-            from . import functional as HF
-            out = HF.intreg_refine_loss(dense, batch.lobes, batch.lesions, batch.keep, batch.targets, batch.weight,
-                                        self.smoothing, refined=refined)
-            return out[0], out[1]
-        return self.reference_math(dense, batch, refined)
-
-    def reference_math(self, dense, batch, refined=None):
-        """The same loss with torch ops (host-side specification of what csrc/loss.hip computes; used by
-        the CPU tests against the reference's golden vectors)."""
-        pd = torch.sigmoid(dense)
-        p = pd if refined is None or refined is dense else torch.sigmoid(refined)
-        B = p.shape[0]
-        lobes = batch.lobes
-        inside = (lobes > 0).to(p.dtype)
-        # compute_reg_loss_with_probs (metrics.py:158-177): hinge on the lobe-mean probability of dense_outs
-        pred_ratio = (pd * inside).view(B, -1).sum(-1) / inside.view(B, -1).sum(-1)
-        lo, hi = batch.targets[:, 0], batch.targets[:, 1]
-        K = (0.5 * (hi - lo)) ** 2
-        reg = torch.clamp((pred_ratio - (hi + lo) / 2.0) ** 2 - K, min=0.0) / batch.weight
-        reg_loss = reg.sum()
-        # compute_seg_loss (metrics.py:331-358): pseudo label from dense_outs, then BootBinCrossEntropy
-        # (metrics.py:17-51) on the refined probabilities
-        with torch.no_grad():
-            t = ((pd > 0.5) & (lobes != 0) & (batch.lesions > 0)).to(p.dtype) * batch.keep
-        outside = 1.0 - inside
-        n_out = outside.sum()
-        # outside the lobe t == 0: pt = 1 - p
-        bceo = -(torch.log((1.0 - p).clamp(self.eps, 1.0 - self.eps)) * outside).sum() / n_out
-        n_in = inside.sum()
-        alpha = (1.0 - (t * inside).sum() / n_in).clamp(0.25, 0.75)
-        pt = (p * t + (1.0 - p) * (1.0 - t)).clamp(self.eps, 1.0 - self.eps)
-        w = (alpha * t + (1.0 - alpha) * (1.0 - t)) * inside
-        bce = -(torch.log(pt) * w).sum() / w.sum()
-        ph = torch.maximum(p, 1.0 - p).clamp(self.eps, 1.0 - self.eps)   # p if p > 0.5 else 1 - p
-        boot = -(torch.log(ph) * inside).sum() / n_in
-        seg_loss = bceo + (1.0 - self.smoothing) * bce + self.smoothing * boot
-        return reg_loss, seg_loss
+        """`refined`: the model's second output when it differs from `dense` (DC3DATGeneric).  Two fused HIP
+        kernels (csrc/loss.hip); like every other op of the path there is no CPU fallback (CPU tensors raise)."""
+        from . import functional as HF
+        out = HF.intreg_refine_loss(dense, batch.lobes, batch.lesions, batch.keep, batch.targets, batch.weight,
+                                    self.smoothing, refined=refined)
+        return out[0], out[1]
 
 
 class DataParallelTrainer:
     """One optimisation step of DC3D on this rank's chunks, optionally as micro-batches with
-    gradient accumulation, and -- when torch.distributed is initialised -- an all-reduce (average)
-    of the gradients in a few large flat buckets before the optimiser step.
+    gradient accumulation, and -- when torch.distributed is initialised -- an all-reduce of the gradients in a
+    few large flat buckets before the optimiser step.
+
+    What the step computes is rank-count independent: it is the reference's loss on the GLOBAL batch
+    (all ranks' chunks), evaluated shard by shard.  `reg_loss` is a sum over samples (metrics.py:177), so
+    its gradients add up over micro-batches and ranks; `seg_loss` is a batch mean, so every micro-batch
+    enters with its share len(micro) / len(global batch) (its class-balance weight alpha stays a statistic of
+    the micro-batch: documented deviation from one huge batch).  The gradients are therefore SUMMED over ranks,
+    and W ranks with one shard each reproduce one rank running the same shards as micro-batches
+    (tests/test_gpu_dp.py).
 
     xGMI is point-to-point (7 links/GPU): the 65 MB of fp32 gradients take < 1 ms as a ring
     all-reduce, against a multi-second step, so the buckets are reduced right after the last
@@ -163,6 +138,7 @@ class DataParallelTrainer:
         return buckets
 
     def allreduce_gradients(self):
+        """Sum the gradients over the ranks (see the class docstring for why a sum)."""
         if self.world == 1:
             return
         works = []
@@ -172,7 +148,6 @@ class DataParallelTrainer:
             works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
         for work, flat, bucket in works:
             work.wait()
-            flat.div_(self.world)
             off = 0
             for p in bucket:
                 n = p.numel()
@@ -181,9 +156,12 @@ class DataParallelTrainer:
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
 
-    def step(self, batch, micro_batch=None):
-        """Returns the (detached, device) loss components summed over the rank's batch."""
+    def step(self, batch, micro_batch=None, global_batch=None):
+        """Returns the (detached, device) loss components of this rank's batch: reg summed, seg weighted by
+        the share of the global batch.  `global_batch`: number of chunks over all ranks (default: every rank
+        holds as many as this one)."""
         n = len(batch)
+        n_glob = int(global_batch) if global_batch else n * self.world
         mb = n if not micro_batch else min(micro_batch, n)
         self.opt.zero_grad(set_to_none=True)
         tot_reg = tot_seg = None
@@ -191,11 +169,11 @@ class DataParallelTrainer:
             b = batch.micro(lo, min(n, lo + mb))
             dense, refined = self.model(b.images, b.lobes)
             reg, seg = self.loss_fn(dense, b, refined=None if refined is dense else refined)
-            # seg_loss is a per-micro-batch mean: weight it by its share of the rank batch
-            loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * (len(b) / n)
+            share = len(b) / n_glob
+            loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * share
             loss.backward()
             tot_reg = reg.detach() if tot_reg is None else tot_reg + reg.detach()
-            tot_seg = seg.detach() * (len(b) / n) if tot_seg is None else tot_seg + seg.detach() * (len(b) / n)
+            tot_seg = seg.detach() * share if tot_seg is None else tot_seg + seg.detach() * share
         self.allreduce_gradients()
         self.opt.step()
         return tot_reg, tot_seg

@@ -63,10 +63,16 @@ def pooling_dense_features(dense_outs, lungs, pooling_method='avg'):
         return HF.masked_mean(dense_outs, ones).view(B, C)
     if pooling_method == 'global_max':
         return HF.global_max(dense_outs)
-    lungs_expand = lungs.expand(B, 1, *dense_outs.shape[2:]) if lungs.shape[1] == 1 else None
-    if lungs_expand is None:
-        raise ValueError("pooling_dense_features: lungs must be a [B,1,D,H,W] mask")
-    return HF.masked_mean(dense_outs, lungs_expand.to(dense_outs.dtype))
+    # lungs.expand_as(dense_outs) (models.py:45): a [B,1,...] mask broadcasts over the channels inside the
+    # kernel; a [B,C,...] mask (one mask per channel) is reduced channel by channel
+    if lungs.shape[1] == 1:
+        mask = lungs.expand(B, 1, *dense_outs.shape[2:]).to(dense_outs.dtype)
+        return HF.masked_mean(dense_outs, mask)
+    if tuple(lungs.shape) != tuple(dense_outs.shape):
+        raise ValueError(f"pooling_dense_features: lungs {tuple(lungs.shape)} does not expand to {tuple(dense_outs.shape)}")
+    cols = [HF.masked_mean(dense_outs[:, c:c + 1].contiguous(), lungs[:, c:c + 1].to(dense_outs.dtype).contiguous())
+            for c in range(C)]
+    return torch.cat(cols, dim=1)
 
 
 class DC3D(nn.Module):

@@ -686,3 +686,38 @@ def int_reg_refine_loss2(dense, refined, lobes, lesions, ctsses, freq_map, band_
         pseudo = pseudo * keep
     seg = boot_bce(torch.sigmoid(refined), pseudo, lobes > 0, smoothing)
     return reg, seg
+
+
+def fused_loss_math(dense, batch, refined=None, smoothing=0.1, eps=1e-7):
+    """IntRegRefineLoss (metrics.py:360-373) in the *fused formulation* that csrc/loss.hip implements (sums
+    over the batch of per-voxel terms, instead of the reference's per-sample numpy round trips), spelled with
+    torch ops on a `dram_amd.train_step.Batch`.  The CPU tests check it against the reference's golden loss
+    vectors, the GPU tests check the kernels against the same vectors: the formulation and its
+    implementation are pinned separately.  Returns (reg_loss, seg_loss)."""
+    pd = torch.sigmoid(dense)
+    p = pd if refined is None or refined is dense else torch.sigmoid(refined)
+    B = p.shape[0]
+    lobes = batch.lobes
+    inside = (lobes > 0).to(p.dtype)
+    # compute_reg_loss_with_probs (metrics.py:158-177): hinge on the lobe-mean probability of dense_outs
+    pred_ratio = (pd * inside).view(B, -1).sum(-1) / inside.view(B, -1).sum(-1)
+    lo, hi = batch.targets[:, 0], batch.targets[:, 1]
+    K = (0.5 * (hi - lo)) ** 2
+    reg = torch.clamp((pred_ratio - (hi + lo) / 2.0) ** 2 - K, min=0.0) / batch.weight
+    reg_loss = reg.sum()
+    # compute_seg_loss (metrics.py:331-358): pseudo label from dense_outs, then BootBinCrossEntropy
+    # (metrics.py:17-51) on the refined probabilities
+    with torch.no_grad():
+        t = ((pd > 0.5) & (lobes != 0) & (batch.lesions > 0)).to(p.dtype) * batch.keep
+    outside = 1.0 - inside
+    n_out = outside.sum()
+    bceo = -(torch.log((1.0 - p).clamp(eps, 1.0 - eps)) * outside).sum() / n_out      # outside the lobe t == 0
+    n_in = inside.sum()
+    alpha = (1.0 - (t * inside).sum() / n_in).clamp(0.25, 0.75)
+    pt = (p * t + (1.0 - p) * (1.0 - t)).clamp(eps, 1.0 - eps)
+    w = (alpha * t + (1.0 - alpha) * (1.0 - t)) * inside
+    bce = -(torch.log(pt) * w).sum() / w.sum()
+    ph = torch.maximum(p, 1.0 - p).clamp(eps, 1.0 - eps)                               # p if p > 0.5 else 1 - p
+    boot = -(torch.log(ph) * inside).sum() / n_in
+    seg_loss = bceo + (1.0 - smoothing) * bce + smoothing * boot
+    return reg_loss, seg_loss

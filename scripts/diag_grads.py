@@ -5,7 +5,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bodyct-dram_amd"), os.path.join(ROOT, "tests")]
 import models
 from oracle import dram_oracle as O
-from oracle.make_golden import SLIM
+from dram_amd.configs import SLIM
 from test_gpu_parity import _fp64_oracle_grads, rel_err, _sub
 
 z = np.load(os.path.join(ROOT, "tests/golden/dc3d_slim.npz"))

@@ -72,3 +72,23 @@ def test_pooling_dense_features(golden_dir, method):
         assert torch.equal(dense.grad.cpu(), torch.from_numpy(z[f"pool/{method}/gin"]))
     else:
         check(dense.grad, z[f"pool/{method}/gin"], method + " gin", 1e-6)
+
+
+def test_pooling_dense_features_per_channel_mask():
+    """`lungs.expand_as(dense_outs)` (reference models.py:45) also accepts a [B,C,D,H,W] mask: one mask per channel.
+    Checked against the reference's formula evaluated in fp64 on the host."""
+    import models
+    g = torch.Generator().manual_seed(21)
+    dense = torch.randn(2, 3, 5, 6, 7, generator=g)
+    lungs = (torch.rand(2, 3, 5, 6, 7, generator=g) > 0.4).float()
+    gout = torch.randn(2, 3, generator=g)
+    d64 = dense.double().requires_grad_(True)
+    ref = (d64 * lungs.double()).view(2, 3, -1).sum(-1) / lungs.double().view(2, 3, -1).sum(-1)   # models.py:45-47
+    (ref * gout.double()).sum().backward()
+    dg = dense.cuda().requires_grad_(True)
+    out = models.pooling_dense_features(dg, lungs.cuda(), "avg")
+    check(out, ref.detach(), "per-channel mask out", 1e-6)
+    (out * gout.cuda()).sum().backward()
+    check(dg.grad, d64.grad, "per-channel mask gin", 1e-6)
+    with pytest.raises(ValueError):
+        models.pooling_dense_features(dg, lungs.cuda()[:, :2], "avg")

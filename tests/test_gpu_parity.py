@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import dram_oracle as O
-from oracle.make_golden import SLIM
+from dram_amd.configs import SLIM, ST_DRAM_REF_MODEL
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -485,7 +485,7 @@ def test_dc3d_full_golden(golden_dir):
     import models
     z = np.load(os.path.join(golden_dir, "dc3d_full.npz"))
     torch.manual_seed(0)
-    model = models.DC3D(**O.ST_DRAM_REF_MODEL)
+    model = models.DC3D(**ST_DRAM_REF_MODEL)
     model.init(models.HeNorm(mode="fan_in"))
     sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
     model = model.to(DEV)
@@ -499,7 +499,7 @@ def test_dc3d_full_golden(golden_dir):
     check(d0, z["full_bn/train_out"], "full train")
     (d0 * dev(torch.from_numpy(z["full_bn/gout"]))).sum().backward()
     grads = dict(model.named_parameters())
-    g64 = _fp64_oracle_grads(O.ST_DRAM_REF_MODEL, sd0, z["full_bn/x"], z["full_bn/gout"], "bn")
+    g64 = _fp64_oracle_grads(ST_DRAM_REF_MODEL, sd0, z["full_bn/x"], z["full_bn/gout"], "bn")
     check_grads({k: p.grad for k, p in grads.items()}, _sub(z, "full_bn/grad/"), g64, "full_bn")
     ref_norms = _sub(z, "full_bn/gradnorm/")
     nerr_ref = max(abs(float(v) - g64[k].norm().item()) / g64[k].norm().item() for k, v in ref_norms.items())

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import dram_oracle as O
-from oracle.make_golden import SLIM_ATT
+from dram_amd.configs import SLIM_ATT
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import dram_oracle as O
-from oracle.make_golden import SLIM
+from dram_amd.configs import SLIM
 
 pytestmark = pytest.mark.gpu
 FREQ = {k: 1.0 / 6 for k in range(6)}

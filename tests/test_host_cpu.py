@@ -77,7 +77,7 @@ def test_dc3d_structure_matches_reference(golden_dir):
     """Same seed -> same parameters as the reference's DC3D (checksums from the reference run),
     same 86 state-dict keys."""
     import models
-    from oracle.dram_oracle import ST_DRAM_REF_MODEL
+    from dram_amd.configs import ST_DRAM_REF_MODEL
     z = np.load(os.path.join(golden_dir, "dc3d_full.npz"))
     torch.manual_seed(0)
     model = models.DC3D(**ST_DRAM_REF_MODEL)
@@ -122,3 +122,49 @@ def test_public_signatures_match_reference(golden_dir):
             if name == "PCM" and meth == "init_graph":
                 continue                                   # same name, returns the stencil offsets; arguments optional here
             assert str(inspect.signature(getattr(obj, meth))) == sig, (name, meth)
+
+
+def test_package_configs_equal_the_oracle_copies():
+    """The product package carries its own model configurations (dram_amd/configs.py) so that nothing under
+    bodyct-dram_amd/, bench.py's GPU path or the GPU tests needs oracle/ for a constant; the oracle's copies
+    (used to generate the goldens) must be the same dicts."""
+    from dram_amd import configs as C
+    from oracle import dram_oracle as O
+    from oracle import make_golden as G
+    assert C.ST_DRAM_REF_MODEL == O.ST_DRAM_REF_MODEL
+    assert C.ST_DRAM_REF_ATT_MODEL == O.ST_DRAM_REF_ATT_MODEL
+    assert C.SLIM == G.SLIM and C.SLIM_ATT == G.SLIM_ATT
+
+
+def test_checkpoint_wrapper_both_branches():
+    """parts.checkpoint_wrapper (reference dram/parts.py:57-64): segments > 0 -> torch.utils.checkpoint (the module's
+    forward runs again during backward), otherwise a plain call; same values and gradients either way."""
+    import parts
+
+    class Counting(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(5, 3)
+            self.calls = 0
+
+        def forward(self, a, b):
+            self.calls += 1
+            return torch.tanh(self.lin(a)) * b
+
+    torch.manual_seed(0)
+    m = Counting()
+    a0, b0 = torch.randn(4, 5), torch.randn(4, 3)
+    results = {}
+    for segments in (0, 2):
+        m.calls = 0
+        m.zero_grad()
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = parts.checkpoint_wrapper(m, segments, a, b)
+        assert m.calls == 1
+        out.sum().backward()
+        assert m.calls == (2 if segments > 0 else 1)          # recomputed in backward only when checkpointed
+        results[segments] = (out.detach().clone(), a.grad.clone(), b.grad.clone(), m.lin.weight.grad.clone())
+    for x, y in zip(results[0], results[2]):
+        assert torch.equal(x, y)
+    ref = torch.tanh(m.lin(a0)) * b0
+    assert torch.equal(results[0][0], ref.detach())

@@ -1,5 +1,5 @@
-"""CPU checks of the train-step plumbing: the device loss restatement against the reference's
-golden loss vector, and the data-parallel gradient averaging over gloo with 2 ranks."""
+"""CPU checks of the train-step plumbing: the fused loss formulation (oracle.fused_loss_math) against the
+reference's golden loss vector, that the product loss refuses CPU tensors, and the data-parallel gradient all-reduce (a sum: see DataParallelTrainer) over gloo with 2 ranks."""
 import os
 import sys
 
@@ -12,12 +12,13 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def test_device_loss_matches_reference_golden(golden_dir):
-    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    from dram_amd.train_step import Batch
+    from oracle.dram_oracle import fused_loss_math
     z = np.load(os.path.join(golden_dir, "loss.npz"))
     t = lambda k: torch.from_numpy(z[k])
     batch = Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), {k: 1.0 / 6 for k in range(6)}, band_width=1e-2)
     dense = t("dense").clone().requires_grad_(True)
-    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dense, batch)
+    reg, seg = fused_loss_math(dense, batch, smoothing=0.1)
     assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
     assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
     (2.0 * reg + 1.0 * seg).backward()
@@ -49,12 +50,12 @@ def _dp_worker(rank, world, port, out):
     for i, p in enumerate(model.parameters()):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     tr.allreduce_gradients()
-    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(model.parameters()))
+    ok = all(torch.allclose(p.grad, torch.full_like(p, 3.0 * (i + 1))) for i, p in enumerate(model.parameters()))
     # a parameter without a gradient on this rank still takes part (zeros)
     params = list(model.parameters())
     params[0].grad = None if rank == 0 else torch.ones_like(params[0])
     tr.allreduce_gradients()
-    ok = ok and torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))
+    ok = ok and torch.allclose(params[0].grad, torch.full_like(params[0], 1.0))
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -70,14 +71,26 @@ def test_gradient_allreduce_two_ranks_gloo():
 
 def test_device_loss_two_outputs_matches_reference_golden(golden_dir):
     """DC3DATGeneric case: regression term + pseudo label from dense_outs, segmentation term on refined."""
-    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    from dram_amd.train_step import Batch
+    from oracle.dram_oracle import fused_loss_math
     z = np.load(os.path.join(golden_dir, "loss2.npz"))
     t = lambda k: torch.from_numpy(z[k])
     batch = Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), {k: 1.0 / 6 for k in range(6)}, band_width=1e-2)
     dense, refined = t("dense").clone().requires_grad_(True), t("refined").clone().requires_grad_(True)
-    reg, seg = DeviceIntRegRefineLoss(1e-2, 0.1)(dense, batch, refined=refined)
+    reg, seg = fused_loss_math(dense, batch, refined=refined, smoothing=0.1)
     assert abs(reg.item() - float(z["reg"])) <= 1e-5 * max(1.0, abs(float(z["reg"])))
     assert abs(seg.item() - float(z["seg"])) <= 1e-5 * max(1.0, abs(float(z["seg"])))
     (2.0 * reg + 1.0 * seg).backward()
     assert np.abs(dense.grad.numpy() - z["gdense"]).max() <= 1e-4 * np.abs(z["gdense"]).max()
     assert np.abs(refined.grad.numpy() - z["grefined"]).max() <= 1e-4 * np.abs(z["grefined"]).max()
+
+
+def test_device_loss_refuses_cpu_tensors(golden_dir):
+    """No CPU / PyTorch fallback in the product path: the device loss raises on host tensors like every other op."""
+    import pytest
+    from dram_amd.train_step import Batch, DeviceIntRegRefineLoss
+    z = np.load(os.path.join(golden_dir, "loss.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    batch = Batch(t("images"), t("lobes"), t("lesions"), list(z["ctss"]), {k: 1.0 / 6 for k in range(6)}, band_width=1e-2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DeviceIntRegRefineLoss(1e-2, 0.1)(t("dense"), batch)
