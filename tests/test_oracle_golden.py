@@ -197,3 +197,23 @@ def test_loss_two_outputs(golden_dir):
     (2.0 * reg + 1.0 * seg).backward()
     _close(dense.grad, z["gdense"], rtol=1e-4, atol=1e-6)
     _close(refined.grad, z["grefined"], rtol=1e-4, atol=1e-6)
+
+
+def test_dc3d_clean_fixture(golden_dir):
+    """The well-conditioned BatchNorm fixture (oracle/make_golden.py:gen_clean: no pre-activation within 1e-4 sigma
+    of zero, so no ReLU-mask flips between fp32 implementations): the oracle's fp32 gradients equal the reference's
+    on EVERY parameter tensor to rounding, early layers included."""
+    z = _load(golden_dir, "dc3d_clean")
+    tag = "slim_bn_clean"
+    assert float(z[tag + "/margin"]) >= 1e-4 and float(z[tag + "/ref_fp32_vs_fp64"]) < 1e-4
+    params, buffers = O.split_state_dict({k: _t(v) for k, v in _sub(z, tag + "/sd/").items()})
+    for p in params.values():
+        p.requires_grad_(True)
+    out = O.dc3d_forward(SLIM, params, buffers, _t(z[tag + "/x"]), training=True, norm_method="bn")
+    _close(out, z[tag + "/train_out"], rtol=1e-4, atol=1e-5)
+    (out * _t(z[tag + "/gout"])).sum().backward()
+    grads = _sub(z, tag + "/grad/")
+    assert len(grads) == len(params)
+    for k, gref in grads.items():
+        err = np.abs(params[k].grad.numpy() - gref).max() / np.abs(gref).max()
+        assert err <= 1e-4, (k, err)
