@@ -245,7 +245,8 @@ def main():
                                 "multiply-adds per channel pair and voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = "
                                 "direct-conv FLOPs of SURVEY 8(d) / time"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
-            if os.path.exists(pmc):
+            # (collected on micro-batches of 16 x 128^3: only that workload has the same launches)
+            if os.path.exists(pmc) and (args.size, min(args.micro, args.chunks)) == (128, 16):
                 try:
                     t = json.load(open(pmc)).get(dom)
                     if t:

@@ -7,6 +7,12 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
+# torch FIRST: it bundles its own libamdhip64.so (soname libamdhip64.so.7).  Loaded after torch, libdram_hip.so binds
+# to that already-mapped runtime, i.e. to the one that owns the device buffers and streams it is handed.  Loaded
+# before torch, the dynamic loader resolves the soname to /opt/rocm's copy instead and torch then maps its own on
+# top: two HIP runtimes in one process, and every launch from this library fails ("no ROCm-capable device").
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdram_hip.so")
 

@@ -168,3 +168,18 @@ def test_checkpoint_wrapper_both_branches():
         assert torch.equal(x, y)
     ref = torch.tanh(m.lin(a0)) * b0
     assert torch.equal(results[0][0], ref.detach())
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libdram_hip.so must bind to the HIP runtime torch brought (the one that owns the buffers and streams it is
+    handed).  Imported before torch it used to pull /opt/rocm's libamdhip64 next to torch's bundled copy: two runtimes
+    in one process, every launch failing with "no ROCm-capable device" (seen in round 2 through
+    `python __graft_entry__.py smoke`, whose build() imports the package first)."""
+    import subprocess
+    import sys
+    code = ("import sys, re; sys.path.insert(0, %r); import dram_amd; import torch; "
+            "libs = sorted(set(re.findall(r'\\S*libamdhip64\\S*', open('/proc/self/maps').read()))); "
+            "print(len(libs), libs)" % os.path.join(ROOT, "bodyct-dram_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
