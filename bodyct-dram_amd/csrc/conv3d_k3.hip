@@ -57,6 +57,16 @@ struct ConvArgs {
     const float* bias;  // [Cout] or null
     int N, Cin, Cout, D, H, W;
     int nbx, nby, nbz, co_tiles;
+    // "normalise + ReLU on load": source tensor k is the RAW output y of the producing conv and the operand of
+    // this conv is act_k(coefk[row][0] * y + coefk[row][1]) per (n, c) row, ReLU if reluk (coefk null: the tensor
+    // is used as it is).  The activated tensor of the norm -> ReLU between two convs is then never written.
+    const float* coef1;
+    const float* coef2;
+    int relu1, relu2;
+    // BatchNorm / GroupNorm statistics of the OUTPUT in the epilogue: per (row, box, wave) {mean, M2, count} of the
+    // wave's 64 outputs of that channel -> stats[(row * nparts + part) * 3]; null: not wanted.
+    float* stats;
+    int nparts;
 };
 
 constexpr int KC = 4;  // input channels per LDS stage
@@ -110,13 +120,126 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Exchange with the lane `M` away inside each half of the wave (M = 1, 2, 4, 8, 16): ds_swizzle in bit-mask mode
+// (and 0x1f, or 0, xor M) -- no address register, unlike the ds_bpermute behind __shfl_xor.
+template <int M>
+__device__ __forceinline__ float swz_xor(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1f | (M << 10)));
+}
+
+// Sum a per-lane array over the 32 lanes that share lane>>5 ("half" of the wave = the 32 positions of a 32x32 MFMA
+// tile), for NREG = 16 or 32 registers at once: each step exchanges half of the live registers with the lane
+// H away and keeps the other half, so NREG registers cost NREG - 1 (+16 for NREG = 16) exchanges instead of
+// 5 * NREG.  On return x[0] of lane j holds the sum over its half of register (j % NREG).
+template <int H, int NREG>
+__device__ __forceinline__ void transpose_reduce_step(float (&x)[NREG], int lane) {
+    const bool up = (lane & H) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const float keep = up ? x[i + H] : x[i];
+        const float send = up ? x[i] : x[i + H];
+        x[i] = keep + swz_xor<H>(send);
+    }
+}
+template <int NREG>
+__device__ __forceinline__ void lane_transpose_reduce(float (&x)[NREG], int lane) {
+    static_assert(NREG == 16 || NREG == 32, "16 or 32 registers");
+    if (NREG == 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] += swz_xor<16>(x[i]);
+    } else {
+        transpose_reduce_step<(NREG == 32 ? 16 : 8)>(x, lane);
+    }
+    transpose_reduce_step<8>(x, lane);
+    transpose_reduce_step<4>(x, lane);
+    transpose_reduce_step<2>(x, lane);
+    transpose_reduce_step<1>(x, lane);
+}
+// The inverse: lane j holds in x[0] the value that belongs to register (j % NREG); on return every lane of the
+// half holds all NREG values, x[i] = the value of register i.
+template <int H, int NREG>
+__device__ __forceinline__ void transpose_broadcast_step(float (&x)[NREG], int lane) {
+    const bool up = (lane & H) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const float mine = x[i], theirs = swz_xor<H>(mine);
+        x[i] = up ? theirs : mine;
+        x[i + H] = up ? mine : theirs;
+    }
+}
+template <int NREG>
+__device__ __forceinline__ void lane_transpose_broadcast(float (&x)[NREG], int lane) {
+    transpose_broadcast_step<1>(x, lane);
+    transpose_broadcast_step<2>(x, lane);
+    transpose_broadcast_step<4>(x, lane);
+    transpose_broadcast_step<8>(x, lane);
+    if (NREG == 32) transpose_broadcast_step<(NREG == 32 ? 16 : 8)>(x, lane);
+}
+
+// Statistics of a conv output tile in the epilogue (BatchNorm / GroupNorm moments without a pass over the tensor).
+// A lane holds, for each of its NREG = 16*COT accumulator registers i (channel ch(i) below) two outputs Y(0,i),
+// Y(1,i) (valid if ok0 / ok1).  Per wave half and channel: two-pass {mean, M2} over the <= 64 valid values
+// (mean first, then squared deviations from it: no E[x^2] - E[x]^2 cancellation), written with the count to
+// part[(row * nparts + pidx) * 3].  The partials are combined with Chan's formula in fp64 by norm_finalize_parts.
+template <int COT, typename YF>
+__device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lane, float* __restrict__ stats,
+                                               int64_t row0, int co0, int Cout, int nparts, int pidx) {
+    constexpr int NREG = 16 * COT;
+    const int j = lane & 31, kh = lane >> 5;
+    const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    const float nvalid = (float)(__popcll(__ballot(ok0) & half) + __popcll(__ballot(ok1) & half));
+    float s[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) s[i] = (ok0 ? Y(0, i) : 0.f) + (ok1 ? Y(1, i) : 0.f);
+    lane_transpose_reduce<NREG>(s, lane);
+    const float mean_j = nvalid > 0.f ? s[0] / nvalid : 0.f;
+    __builtin_amdgcn_sched_barrier(0);     // keep the two phases apart: the sums are dead before the deviations are born
+    float q[NREG];
+    q[0] = mean_j;
+    lane_transpose_broadcast<NREG>(q, lane);                      // q[i] = mean of register i's channel
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const float d0 = Y(0, i) - q[i], d1 = Y(1, i) - q[i];
+        q[i] = (ok0 ? d0 * d0 : 0.f) + (ok1 ? d1 * d1 : 0.f);
+    }
+    lane_transpose_reduce<NREG>(q, lane);
+    const int i = j % NREG;
+    const int co = co0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * kh;   // channel of register i (MFMA 32x32 layout)
+    if (j < NREG && co < Cout) {
+        float* o = stats + ((row0 + co) * (int64_t)nparts + pidx) * 3;
+        o[0] = mean_j;
+        o[1] = q[0];
+        o[2] = nvalid;
+    }
+}
+
+// Operand transform of a lazily normalised source (ConvArgs::coef1/2): per K-chunk channel the wave-uniform
+// {a, b, lo}: v -> max(a*v + b, lo), lo = 0 with ReLU and -inf without; identity {1, 0, -inf} for a plain source,
+// {0, 0, 0} for the channel tail beyond Cin.
+struct LazyCoef {
+    float a, b, lo;
+};
+__device__ __forceinline__ LazyCoef lazy_coef(const ConvArgs& a, int n, int ci) {
+    LazyCoef c;
+    if (ci >= a.Cin) { c.a = 0.f; c.b = 0.f; c.lo = 0.f; return c; }
+    const bool first = ci < a.src.C1;
+    const float* cf = first ? a.coef1 : a.coef2;
+    const int relu = first ? a.relu1 : a.relu2;
+    if (cf == nullptr) { c.a = 1.f; c.b = 0.f; c.lo = -INFINITY; return c; }
+    const int64_t row = first ? (int64_t)n * a.src.C1 + ci : (int64_t)n * a.src.C2 + (ci - a.src.C1);
+    c.a = cf[2 * row];
+    c.b = cf[2 * row + 1];
+    c.lo = relu ? 0.f : -INFINITY;
+    return c;
+}
+
 // Software pipeline (one barrier per K chunk): while the MFMAs of chunk c run out of LDS stage
 // c&1, the global loads of chunk c+1 are in flight into registers; they are written to the other
 // stage after the MFMAs and become visible at the barrier.  Inside a chunk the LDS operand reads
 // of k-step s+1 are issued ahead of the MFMAs of k-step s (two operand register sets).  Two blocks
 // (2 x 80 KB of LDS, 2 waves per SIMD) share a CU, so one block's write/barrier phase is covered
 // by the other's MFMAs.
-template <int BX, int BY, int BZ, int COT>
+template <int BX, int BY, int BZ, int COT, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     static_assert(BX * BY * BZ == 256, "block covers 256 voxels");
     using G = FwdGeom<BX, BY, BZ, COT>;
@@ -189,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 
     float rin[KC][NQ];   // prefetched input halo elements of the next chunk
     f32x4 rw[WPASS];     // prefetched weights of the next chunk
+    const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);   // normalise + ReLU on load (block-uniform)
+    LazyCoef lc[KC];     // the chunk's operand transforms (wave-uniform: scalar registers)
 
     auto load_chunk = [&](int c0) {
 #pragma unroll
@@ -201,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
             const u32x4 off = first ? off1 : off2;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rin[kc][q] = buf_load(srd, off[q], 0);
+            if (lazy) lc[kc] = lazy_coef(a, n, ci);
         }
         const unsigned cbase = 4u * (unsigned)c0 * (unsigned)a.Cout;
         if (c0 + KC <= a.Cin) {
@@ -214,6 +340,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
     auto store_chunk = [&](float* stage) {
         float* lin = stage;
         float* lw = stage + KC * PS;
+        if (lazy) {   // the zero padding belongs to the ACTIVATED tensor: out-of-volume halo elements stay 0
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    rin[kc][q] = off1[q] != OOB ? fmaxf(fmaf(lc[kc].a, rin[kc][q], lc[kc].b), lc[kc].lo) : 0.f;
+        }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -271,12 +404,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 
     // ---- epilogue: accumulator register r of lane (j,kh) = channel (r&3)+8(r>>2)+4kh, voxel j ----
     const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
+    bool okt[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int v = 32 * (2 * wave + t) + j;
         const int vx = v % BX, vy = (v / BX) % BY, vz = v / (BX * BY);
         const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
-        if (gx >= W || gy >= H || gz >= D) continue;
+        okt[t] = gx < W && gy < H && gz < D;
         const int sp1 = (gz * H + gy) * W + gx;
         const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
 #pragma unroll
@@ -286,14 +420,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
                 const int co = co0 + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (co < a.Cout) {
                     float val = acc[c][t][r];
-                    if (a.bias) val += a.bias[co];
-                    if (co < a.dst.C1)
-                        a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
-                    else
-                        a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                    if (a.bias) val += a.bias[co];          // (never together with statistics: checked by the host)
+                    if (okt[t]) {
+                        if (co < a.dst.C1)
+                            a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
+                        else
+                            a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                    }
                 }
             }
         }
+    }
+    if (FUSED && a.stats) {
+        const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + wave;
+        stats_epilogue<COT>([&](int t, int i) { return acc[i >> 4][t][i & 15]; }, okt[0], okt[1], lane, a.stats,
+                            (int64_t)n * a.Cout, co0, a.Cout, a.nparts, pidx);
     }
 }
 
@@ -327,7 +468,7 @@ struct FwdWzGeom {
     static constexpr size_t LDS_BYTES = (size_t)(2 * IN_STAGE + WROWS * COB) * sizeof(float);
 };
 
-template <int BX, int BY, int COT>
+template <int BX, int BY, int COT, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
     static_assert(BX * BY <= 128 && BX * BY > 96, "block covers (up to) 128 (y,x) positions of two z planes; lanes past BX*BY idle");
     using G = FwdWzGeom<BX, BY, COT>;
@@ -397,6 +538,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 
     float rin[KC][4];
     f32x4 rw[WPASS];
+    const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);   // normalise + ReLU on load (block-uniform)
+    LazyCoef lc[KC];     // the chunk's operand transforms (wave-uniform: scalar registers)
 
     auto load_chunk = [&](int c0) {
 #pragma unroll
@@ -409,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
             const u32x4 off = first ? off1 : off2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) rin[kc][q] = buf_load(srd, off[q], 0);
+            if (lazy) lc[kc] = lazy_coef(a, n, ci);
         }
         const unsigned cbase = 4u * (unsigned)c0 * (unsigned)a.Cout;
         if (c0 + KC <= a.Cin) {
@@ -421,6 +565,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
     };
     auto store_in = [&](float* lin) {     // B^T d of the four planes
         if (tid < HP) {
+            if (lazy) {   // the zero padding belongs to the ACTIVATED tensor: out-of-volume halo elements stay 0
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rin[kc][q] = off1[q] != OOB ? fmaxf(fmaf(lc[kc].a, rin[kc][q], lc[kc].b), lc[kc].lo) : 0.f;
+            }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 const float d0 = rin[kc][0], d1 = rin[kc][1], d2 = rin[kc][2], d3 = rin[kc][3];
@@ -486,27 +637,70 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
     // ---- epilogue: A^T m per accumulator element, then the same stores as the direct kernel ----
     const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
     const int gx = x0 + vx, gy = y0 + vy;
-    if (pos < BX * BY && gx < W && gy < H) {
+    const bool lane_ok = pos < BX * BY && gx < W && gy < H;
+    if (!FUSED || a.stats == nullptr) {
+        if (lane_ok) {
 #pragma unroll
-        for (int zz = 0; zz < 2; ++zz) {
-            const int gz = z0 + zz;
-            if (gz >= D) continue;
-            const int sp1 = (gz * H + gy) * W + gx;
-            const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
+            for (int zz = 0; zz < 2; ++zz) {
+                const int gz = z0 + zz;
+                if (gz >= D) continue;
+                const int sp1 = (gz * H + gy) * W + gx;
+                const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
 #pragma unroll
-            for (int c = 0; c < COT; ++c) {
+                for (int c = 0; c < COT; ++c) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (co < a.Cout) {
-                        float val = zz == 0 ? (acc[c][0][r] + acc[c][1][r]) + acc[c][2][r]
-                                            : (acc[c][1][r] - acc[c][2][r]) - acc[c][3][r];
-                        if (a.bias) val += a.bias[co];
-                        if (co < a.dst.C1)
-                            a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
-                        else
-                            a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (co < a.Cout) {
+                            float val = zz == 0 ? (acc[c][0][r] + acc[c][1][r]) + acc[c][2][r]
+                                                : (acc[c][1][r] - acc[c][2][r]) - acc[c][3][r];
+                            if (a.bias) val += a.bias[co];
+                            if (co < a.dst.C1)
+                                a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
+                            else
+                                a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                        }
                     }
+                }
+            }
+        }
+        return;
+    }
+    // with statistics: the two output planes go to scalar registers first (same arithmetic, same stores; the four
+    // accumulator tuples are dead from here on), feed the moments, and are stored last
+    float yv[2][16 * COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            yv[0][16 * c + r] = (acc[c][0][r] + acc[c][1][r]) + acc[c][2][r];      // (no bias on this path: a conv
+            yv[1][16 * c + r] = (acc[c][1][r] - acc[c][2][r]) - acc[c][3][r];      //  followed by a norm has none)
+        }
+    }
+    const bool ok0 = lane_ok && z0 < D, ok1 = lane_ok && (z0 + 1) < D;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + wave;
+        stats_epilogue<COT>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, a.stats, (int64_t)n * a.Cout, co0,
+                            a.Cout, a.nparts, pidx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz) {
+        if (!(zz == 0 ? ok0 : ok1)) continue;
+        const int gz = z0 + zz;
+        const int sp1 = (gz * H + gy) * W + gx;
+        const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < a.Cout) {
+                    if (co < a.dst.C1)
+                        a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = yv[zz][16 * c + r];
+                    else
+                        a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = yv[zz][16 * c + r];
                 }
             }
         }
@@ -520,6 +714,11 @@ struct WgradArgs {
     float* slabs;     // [SPLIT][Cout][Cin][27]
     int N, Cin, Cout, D, H, W;
     int nbx, nby, nbz, nboxes, split, ci_tiles, co_tiles;
+    // normalise + ReLU on load of x (see ConvArgs::coef1): source k holds the RAW conv output, the operand is
+    // act(coefk[row][0] * x + coefk[row][1]); Winograd kernel only (the host materialises for the others)
+    const float* coef1;
+    const float* coef2;
+    int relu1, relu2;
 };
 
 template <int HVv>
@@ -960,7 +1159,7 @@ struct WgradWzGeom {
     static constexpr size_t LDS_BYTES = (DOUBLE ? 2 : 1) * (size_t)STAGE * sizeof(float);
 };
 
-template <int BX, int BY, int COS, int CIT>
+template <int BX, int BY, int COS, int CIT, bool LAZY = false>
 __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a) {
     using G = WgradWzGeom<BX, BY, COS, CIT>;
     constexpr int POS = G::POS, RA = G::RA, HXP = G::HXP, PLX = G::PLX, PB = G::PB, STAGE = G::STAGE;
@@ -1004,6 +1203,12 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
     f32x4 rdy[DYP][2];
     f32x4 rxi[XIP][4];
     float rxe[XEP][4];
+    // LAZY: per staged slot the {a, b} of its channel row and the validity of its four planes (the zero padding
+    // belongs to the ACTIVATED tensor: out-of-volume halo elements must stay 0, not act(b))
+    const float* cf = LAZY ? (use2 ? a.coef2 : a.coef1) : nullptr;   // block-uniform; null: this source is plain
+    const float lo = (LAZY && (use2 ? a.relu2 : a.relu1)) ? 0.f : -INFINITY;
+    float cia[XIP], cib[XIP], cea[XEP], ceb[XEP];
+    unsigned imask = 0, emask = 0;
 
     // thread-constant slot roles (see conv3d_k3_wgrad_vec_kernel)
     const int d_c = tid / DY_TPC, d_v = 4 * (tid % DY_TPC);
@@ -1049,11 +1254,13 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
             {
                 const int okr = (int)i_act & (int)((unsigned)(y0 - 1 + i_r) < (unsigned)H);
                 unsigned run[4], inc[4];
+                if (LAZY) imask = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int okq = okr & (int)((unsigned)(z0 - 1 + q) < (unsigned)D);
                     run[q] = okq ? origin + i_rel + (unsigned)q * zss4 : OOB;
                     inc[q] = okq ? (unsigned)XI_CPP * Ss4 : 0u;
+                    if (LAZY) imask |= (unsigned)okq << q;
                 }
 #pragma unroll
                 for (int p = 0; p < XIP; ++p) {
@@ -1063,17 +1270,24 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
                         rxi[p][q] = buf_load4(srd, in ? run[q] : OOB, 0);
                         run[q] += inc[q];
                     }
+                    if (LAZY && cf) {
+                        const int ch = min(cs0 + i_c + p * XI_CPP, Cs - 1);       // (clamped: tail slots are never stored)
+                        const float2 ab = *reinterpret_cast<const float2*>(cf + 2 * ((int64_t)n * Cs + ch));
+                        cia[p] = ab.x; cib[p] = ab.y;
+                    }
                 }
             }
             {
                 const int okr = (int)e_act & (int)((unsigned)(y0 - 1 + e_r) < (unsigned)H) &
                                 (e_side ? (int)((x0 + BX) < W) : (int)(x0 > 0));
                 unsigned run[4], inc[4];
+                if (LAZY) emask = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int okq = okr & (int)((unsigned)(z0 - 1 + q) < (unsigned)D);
                     run[q] = okq ? origin + e_rel + (unsigned)q * zss4 : OOB;
                     inc[q] = okq ? (unsigned)XE_CPP * Ss4 : 0u;
+                    if (LAZY) emask |= (unsigned)okq << q;
                 }
 #pragma unroll
                 for (int p = 0; p < XEP; ++p) {
@@ -1082,6 +1296,11 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
                     for (int q = 0; q < 4; ++q) {
                         rxe[p][q] = buf_load(srd, in ? run[q] : OOB, 0);
                         run[q] += inc[q];
+                    }
+                    if (LAZY && cf) {
+                        const int ch = min(cs0 + e_c + p * XE_CPP, Cs - 1);
+                        const float2 ab = *reinterpret_cast<const float2*>(cf + 2 * ((int64_t)n * Cs + ch));
+                        cea[p] = ab.x; ceb[p] = ab.y;
                     }
                 }
             }
@@ -1107,7 +1326,16 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
         } else if (piece < DYP + XIP) {
             const int p = piece - DYP;
             if (i_act && (XIP * XI_CPP == CI_B || i_c + p * XI_CPP < CI_B)) {
-                const f32x4 d0 = rxi[p][0], d1 = rxi[p][1], d2 = rxi[p][2], d3 = rxi[p][3];
+                f32x4 dq[4] = {rxi[p][0], rxi[p][1], rxi[p][2], rxi[p][3]};
+                if (LAZY && cf) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool okq = (imask >> q) & 1u;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) dq[q][u] = okq ? fmaxf(fmaf(cia[p], dq[q][u], cib[p]), lo) : 0.f;
+                    }
+                }
+                const f32x4 d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
                 const f32x4 pl[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
                 float* d = lx + (i_c + p * XI_CPP) * PB + i_r * HXP + 1 + 4 * i_j;       // interior starts at column 1
 #pragma unroll
@@ -1121,7 +1349,12 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
         } else {
             const int p = piece - DYP - XIP;
             if (e_act && (XEP * XE_CPP == CI_B || e_c + p * XE_CPP < CI_B)) {
-                const float d0 = rxe[p][0], d1 = rxe[p][1], d2 = rxe[p][2], d3 = rxe[p][3];
+                float eq[4] = {rxe[p][0], rxe[p][1], rxe[p][2], rxe[p][3]};
+                if (LAZY && cf) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) eq[q] = ((emask >> q) & 1u) ? fmaxf(fmaf(cea[p], eq[q], ceb[p]), lo) : 0.f;
+                }
+                const float d0 = eq[0], d1 = eq[1], d2 = eq[2], d3 = eq[3];
                 float* d = lx + (e_c + p * XE_CPP) * PB + e_r * HXP + (e_side ? BX + 1 : 0);
                 d[0] = d0 - d2;
                 d[PLX] = d1 + d2;
@@ -1345,18 +1578,18 @@ __global__ void pack_weights_wz_kernel(const float* __restrict__ w, float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int BX, int BY, int COT>
+template <int BX, int BY, int COT, bool FUSED>
 static int launch_fwd_wz_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
     using G = FwdWzGeom<BX, BY, COT>;
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wz_kernel<BX, BY, COT>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd(wz)")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wz_kernel<BX, BY, COT, FUSED>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd(wz)")) return rc;
     a.co_tiles = cdiv(a.Cout, 32 * COT);
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    hipLaunchKernelGGL((conv3d_k3_fwd_wz_kernel<BX, BY, COT>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_k3_fwd_wz_kernel<BX, BY, COT, FUSED>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_fwd(wz)");
 }
 
@@ -1370,23 +1603,26 @@ static int launch_fwd_wz(ConvArgs& a, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    if (a.Cout <= 32) return launch_fwd_wz_cot<BX, BY, 1>(a, (unsigned)nblk, st);
-    return launch_fwd_wz_cot<BX, BY, 2>(a, (unsigned)nblk, st);
+    // the fused variant (operand transform on load / statistics epilogue) is a separate instantiation: the plain
+    // kernel keeps its registers and schedule
+    const bool fused = a.coef1 || a.coef2 || a.stats;
+    if (a.Cout <= 32) return fused ? launch_fwd_wz_cot<BX, BY, 1, true>(a, (unsigned)nblk, st) : launch_fwd_wz_cot<BX, BY, 1, false>(a, (unsigned)nblk, st);
+    return fused ? launch_fwd_wz_cot<BX, BY, 2, true>(a, (unsigned)nblk, st) : launch_fwd_wz_cot<BX, BY, 2, false>(a, (unsigned)nblk, st);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int BX, int BY, int BZ, int COT>
+template <int BX, int BY, int BZ, int COT, bool FUSED>
 static int launch_fwd_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
     using G = FwdGeom<BX, BY, BZ, COT>;
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_kernel<BX, BY, BZ, COT>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_kernel<BX, BY, BZ, COT, FUSED>, G::LDS_BYTES, lds_once, "conv3d_k3_fwd")) return rc;
     a.co_tiles = cdiv(a.Cout, 32 * COT);
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, COT>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_k3_fwd_kernel<BX, BY, BZ, COT, FUSED>), dim3((unsigned)total), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_fwd");
 }
 
@@ -1400,8 +1636,9 @@ static int launch_fwd(ConvArgs& a, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    if (a.Cout <= 32) return launch_fwd_cot<BX, BY, BZ, 1>(a, (unsigned)nblk, st);
-    return launch_fwd_cot<BX, BY, BZ, 2>(a, (unsigned)nblk, st);
+    const bool fused = a.coef1 || a.coef2 || a.stats;
+    if (a.Cout <= 32) return fused ? launch_fwd_cot<BX, BY, BZ, 1, true>(a, (unsigned)nblk, st) : launch_fwd_cot<BX, BY, BZ, 1, false>(a, (unsigned)nblk, st);
+    return fused ? launch_fwd_cot<BX, BY, BZ, 2, true>(a, (unsigned)nblk, st) : launch_fwd_cot<BX, BY, BZ, 2, false>(a, (unsigned)nblk, st);
 }
 
 // Box shape (all 256 / 64 voxels): the one that pads the volume least; ties go to the first listed.  The reference trains and infers on 80^3 chunks (RESAMPLE_SIZE), whose
@@ -1428,12 +1665,19 @@ static bool use_wz(const ConvArgs& a) {
     return !direct && a.Cin >= 8 && a.D >= 2;
 }
 
-static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
-    if (use_wz(a)) {
+// Which forward kernel / box shape a shape gets (shared by the launch and by dram_conv3d_k3_stats_parts).
+struct FwdChoice {
+    bool wz;
+    int box;            // index into the kernel family's box table
+    int nbx, nby, nbz;  // boxes per sample
+};
+static FwdChoice fwd_choice(const ConvArgs& a) {
+    FwdChoice c;
+    c.wz = use_wz(a);
+    if (c.wz) {
         // position boxes: the padded plane area, weighted by the lanes a box leaves idle (10x10 uses 100 of 128: the
         // 20^3 and 10^3 levels of the reference's 80^3 chunks fit it exactly)
         static const int boxes2[4][2] = {{32, 4}, {16, 8}, {8, 16}, {10, 10}};
-        a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
         int best = 0;
         double best_cost = -1.0;
         for (int i = 0; i < 4; ++i) {
@@ -1443,15 +1687,32 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
         if (const char* f = getenv("DRAM_FWD_BX"))
             for (int i = 0; i < 4; ++i)
                 if (atoi(f) == boxes2[i][0]) best = i;
-        switch (best) {
+        c.box = best;
+        c.nbx = cdiv(a.W, boxes2[best][0]); c.nby = cdiv(a.H, boxes2[best][1]); c.nbz = cdiv(a.D, 2);
+    } else {
+        static const int boxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
+        c.box = pick_box(a.D, a.H, a.W, boxes, 3, "DRAM_FWD_BX");
+        c.nbx = cdiv(a.W, boxes[c.box][0]); c.nby = cdiv(a.H, boxes[c.box][1]); c.nbz = cdiv(a.D, boxes[c.box][2]);
+    }
+    return c;
+}
+
+static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
+    const FwdChoice c = fwd_choice(a);
+    if (a.stats) {
+        DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * 4, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
+                     "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * 4);
+    }
+    if (c.wz) {
+        a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
+        switch (c.box) {
             case 0: return launch_fwd_wz<32, 4>(a, st);
             case 1: return launch_fwd_wz<16, 8>(a, st);
             case 2: return launch_fwd_wz<8, 16>(a, st);
             default: return launch_fwd_wz<10, 10>(a, st);
         }
     }
-    static const int boxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
-    switch (pick_box(a.D, a.H, a.W, boxes, 3, "DRAM_FWD_BX")) {
+    switch (c.box) {
         case 0: return launch_fwd<32, 4, 2>(a, st);
         case 1: return launch_fwd<16, 4, 4>(a, st);
         default: return launch_fwd<8, 8, 4>(a, st);
@@ -1522,14 +1783,19 @@ static int launch_wgrad_vec(WgradArgs& a, hipStream_t st) {
     return check_launch("conv3d_k3_wgrad(vec)");
 }
 
-template <int BX, int BY, int COS, int CIT>
-static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
+template <int BX, int BY, int COS, int CIT, bool LAZY>
+static int launch_wgrad_wz_l(WgradArgs& a, hipStream_t st) {
     using G = WgradWzGeom<BX, BY, COS, CIT>;
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT, LAZY>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT>), dim3(grid), dim3(G::T), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wz_kernel<BX, BY, COS, CIT, LAZY>), dim3(grid), dim3(G::T), G::LDS_BYTES, st, a);
     return check_launch("conv3d_k3_wgrad(wz)");
+}
+template <int BX, int BY, int COS, int CIT>
+static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
+    // the lazy-operand variant is a separate instantiation: the plain kernel keeps its registers and schedule
+    return (a.coef1 || a.coef2) ? launch_wgrad_wz_l<BX, BY, COS, CIT, true>(a, st) : launch_wgrad_wz_l<BX, BY, COS, CIT, false>(a, st);
 }
 
 template <int BX, int BY, int BZ, int COS, int CIT>
@@ -1579,16 +1845,13 @@ extern "C" int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, 
     return check_launch("conv3d_k3_pack_weights");
 }
 
-// Generic entry used by the Python side for forward (dst plain or plain) and
-// backward-data (src plain, dst possibly split into two tensors).
-extern "C" int dram_conv3d_k3_fwd_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2, int oz,
-                                     int oy, int ox, const float* wt, const float* bias, float* y1, int Co1, float* y2,
-                                     int Co2, int yD2, int yH2, int yW2, int yoz, int yoy, int yox, int N, int D,
-                                     int H, int W, void* stream) {
+static int conv_fwd_fill(ConvArgs& a, const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2, int oz, int oy,
+                         int ox, const float* wt, const float* bias, float* y1, int Co1, float* y2, int Co2, int yD2, int yH2,
+                         int yW2, int yoz, int yoy, int yox, int N, int D, int H, int W) {
     DRAM_REQUIRE(x1 && wt && y1, "conv3d_k3_fwd: null pointer");
     DRAM_REQUIRE(C1 > 0 && Co1 > 0 && (x2 == nullptr || C2 > 0) && (y2 == nullptr || Co2 > 0),
                  "conv3d_k3_fwd: bad channel counts");
-    ConvArgs a;
+    a = ConvArgs{};
     a.src = CatView{const_cast<float*>(x1), const_cast<float*>(x2), C1, x2 ? C2 : 0, x2 ? D2 : 1, x2 ? H2 : 1,
                     x2 ? W2 : 1, x2 ? oz : 0, x2 ? oy : 0, x2 ? ox : 0};
     a.dst = CatView{y1, y2, Co1, y2 ? Co2 : 0, y2 ? yD2 : 1, y2 ? yH2 : 1, y2 ? yW2 : 1, y2 ? yoz : 0, y2 ? yoy : 0,
@@ -1603,6 +1866,48 @@ extern "C" int dram_conv3d_k3_fwd_ex(const float* x1, int C1, const float* x2, i
     if (rc) return rc;
     if ((rc = check_cat("conv3d_k3_fwd(src)", a.src, D, H, W))) return rc;
     if ((rc = check_cat("conv3d_k3_fwd(dst)", a.dst, D, H, W))) return rc;
+    return DRAM_OK;
+}
+
+// Generic entry used by the Python side for forward (dst plain or plain) and
+// backward-data (src plain, dst possibly split into two tensors).
+extern "C" int dram_conv3d_k3_fwd_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2, int oz,
+                                     int oy, int ox, const float* wt, const float* bias, float* y1, int Co1, float* y2,
+                                     int Co2, int yD2, int yH2, int yW2, int yoz, int yoy, int yox, int N, int D,
+                                     int H, int W, void* stream) {
+    ConvArgs a;
+    const int rc = conv_fwd_fill(a, x1, C1, x2, C2, D2, H2, W2, oz, oy, ox, wt, bias, y1, Co1, y2, Co2, yD2, yH2, yW2, yoz,
+                                 yoy, yox, N, D, H, W);
+    if (rc) return rc;
+    return conv_fwd_dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W) {
+    if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    ConvArgs a = {};
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    const FwdChoice c = fwd_choice(a);
+    const int64_t parts = (int64_t)c.nbx * c.nby * c.nbz * 4;
+    return parts > 0x7fffffffLL ? 0 : (int)parts;
+}
+
+// Fused forward: each source may be the RAW output of the previous conv with its norm (+ReLU) applied on load
+// (coefK = per-row {a, b}, null = plain tensor), and the statistics of the output are accumulated in the epilogue.
+extern "C" int dram_conv3d_k3_fwd_fused(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2,
+                                        const float* coef2, int relu2, int D2, int H2, int W2, int oz, int oy, int ox,
+                                        const float* wt, const float* bias, float* y, float* stats, int nparts, int N,
+                                        int Cout, int D, int H, int W, void* stream) {
+    ConvArgs a;
+    const int rc = conv_fwd_fill(a, x1, C1, x2, C2, D2, H2, W2, oz, oy, ox, wt, bias, y, Cout, nullptr, 0, 0, 0, 0, 0, 0, 0, N,
+                                 D, H, W);
+    if (rc) return rc;
+    DRAM_REQUIRE(coef2 == nullptr || x2 != nullptr, "conv3d_k3_fwd_fused: coef2 without a second source");
+    DRAM_REQUIRE(stats == nullptr || nparts > 0, "conv3d_k3_fwd_fused: statistics buffer without a partial count");
+    DRAM_REQUIRE(stats == nullptr || bias == nullptr, "conv3d_k3_fwd_fused: output statistics and a bias exclude each other "
+                 "(a convolution that feeds a norm layer has no bias, reference models.py:78)");
+    a.coef1 = coef1; a.coef2 = coef2;
+    a.relu1 = relu1; a.relu2 = relu2;
+    a.stats = stats; a.nparts = nparts;
     return conv_fwd_dispatch(a, (hipStream_t)stream);
 }
 
@@ -1631,11 +1936,21 @@ extern "C" size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D,
     return (size_t)(p.split > q.split ? p.split : q.split) * Cout * Cin * 27 * sizeof(float);
 }
 
-extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
-                                       int oz, int oy, int ox, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                                       int N, int Cout, int D, int H, int W, void* stream) {
+// 1 if backward-weights of this shape can take its x operand lazily (normalise + ReLU on load): the Winograd kernel
+// runs (W % 4 == 0, D >= 2, channel tiles inside one source tensor) and it is not the first-layer kernel.
+extern "C" int dram_conv3d_k3_wgrad_lazy_ok(int N, int C1, int C2, int Cout, int D, int H, int W) {
+    if (N <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (C1 + C2 == 1) return 0;
+    return wgrad_plan(N, C1 + C2, Cout, D, H, W, C2 > 0 ? C1 : 0).wz;
+}
+
+static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2, const float* coef2,
+                     int relu2, int D2, int H2, int W2, int oz, int oy, int ox, const float* dy, float* dw, void* ws,
+                     size_t ws_bytes, int N, int Cout, int D, int H, int W, void* stream) {
     DRAM_REQUIRE(x1 && dy && dw && ws, "conv3d_k3_wgrad: null pointer");
-    WgradArgs a;
+    WgradArgs a = {};
+    a.coef1 = coef1; a.coef2 = x2 ? coef2 : nullptr;
+    a.relu1 = relu1; a.relu2 = relu2;
     a.src = CatView{const_cast<float*>(x1), const_cast<float*>(x2), C1, x2 ? C2 : 0, x2 ? D2 : 1, x2 ? H2 : 1,
                     x2 ? W2 : 1, x2 ? oz : 0, x2 ? oy : 0, x2 ? ox : 0};
     a.dy = dy;
@@ -1648,6 +1963,7 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     if (rc) return rc;
     if ((rc = check_cat("conv3d_k3_wgrad(src)", a.src, D, H, W))) return rc;
     if (a.Cin == 1 && x2 == nullptr) {   // first layer: dedicated kernel
+        DRAM_REQUIRE(a.coef1 == nullptr, "conv3d_k3_wgrad_fused: the first-layer kernel (Cin = 1) takes a plain input");
         DRAM_REQUIRE(((int64_t)Cout + 32) * (int64_t)D * H * W < 0x3fffffffLL,
                      "conv3d_k3_wgrad: (channels + 32) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
         WgradC1Args c;
@@ -1673,6 +1989,9 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     DRAM_REQUIRE(((int64_t)(a.Cin > Cout ? a.Cin : Cout) + 128) * (int64_t)D * H * W < 0x3fffffffLL,
                  "conv3d_k3_wgrad: (channels + 128) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
     const WgradPlan p = wgrad_plan(N, a.Cin, Cout, D, H, W, x2 ? C1 : 0);
+    DRAM_REQUIRE(p.wz || (a.coef1 == nullptr && a.coef2 == nullptr),
+                 "conv3d_k3_wgrad_fused: this shape runs a kernel without the lazy-operand path "
+                 "(dram_conv3d_k3_wgrad_lazy_ok): materialise x first");
     const size_t need = (size_t)p.split * Cout * a.Cin * 27 * sizeof(float);
     if (ws_bytes < need) {
         set_error("conv3d_k3_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1712,6 +2031,22 @@ extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2,
     const int64_t E = (int64_t)Cout * a.Cin * 27;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, a.slabs, dw, E, p.split);
     return check_launch("conv3d_k3_wgrad(reduce)");
+}
+
+extern "C" int dram_conv3d_k3_wgrad_ex(const float* x1, int C1, const float* x2, int C2, int D2, int H2, int W2,
+                                       int oz, int oy, int ox, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                                       int N, int Cout, int D, int H, int W, void* stream) {
+    return wgrad_run(x1, C1, nullptr, 0, x2, C2, nullptr, 0, D2, H2, W2, oz, oy, ox, dy, dw, ws, ws_bytes, N, Cout, D, H, W,
+                     stream);
+}
+
+// Backward-weights whose x operand is act(coef * raw + ...) applied on load (see dram_conv3d_k3_fwd_fused).
+extern "C" int dram_conv3d_k3_wgrad_fused(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2,
+                                          const float* coef2, int relu2, int D2, int H2, int W2, int oz, int oy, int ox,
+                                          const float* dy, float* dw, void* ws, size_t ws_bytes, int N, int Cout, int D,
+                                          int H, int W, void* stream) {
+    return wgrad_run(x1, C1, coef1, relu1, x2, C2, coef2, relu2, D2, H2, W2, oz, oy, ox, dy, dw, ws, ws_bytes, N, Cout, D, H, W,
+                     stream);
 }
 
 extern "C" int dram_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, int N,

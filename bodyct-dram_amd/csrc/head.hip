@@ -13,10 +13,13 @@ namespace dram {
 
 constexpr int MAXCO = 8;  // output channels handled per pass
 
+// `coef` (optional): x holds a RAW conv output and the operand is act(a*x + b) per (n,c) row, ReLU if `relu`
+// ("normalise + ReLU on load", see csrc/conv3d_k3.hip ConvArgs::coef1; same fmaf / fmaxf as everywhere)
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          int Cin, int Cout, int co0, int nco, int64_t S) {
+                                                          int Cin, int Cout, int co0, int nco, int64_t S,
+                                                          const float* __restrict__ coef, int relu) {
     const int n = blockIdx.y;
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
     if (e >= S) return;
@@ -34,6 +37,12 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restric
             xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
         } else {
             xv[0] = xp[(int64_t)c * S]; xv[1] = xv[2] = xv[3] = 0.f;
+        }
+        if (coef) {
+            const float ca = coef[2 * ((int64_t)n * Cin + c)], cb = coef[2 * ((int64_t)n * Cin + c) + 1];
+            const float lo = relu ? 0.f : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = fmaxf(fmaf(ca, xv[u], cb), lo);
         }
 #pragma unroll
         for (int o = 0; o < MAXCO; ++o) {
@@ -107,7 +116,7 @@ constexpr int WG_VPB = 256 * WG_VPT;      // voxels per block
 
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ part, int Cin, int Cout, int64_t S,
-                                                            int nblk) {
+                                                            int nblk, const float* __restrict__ coef, int relu) {
     __shared__ float red[4];
     const int n = blockIdx.y, blk = blockIdx.x;
     const int64_t base = (int64_t)blk * WG_VPB;
@@ -125,10 +134,16 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
         if (threadIdx.x == 0) prow[Cin] = gs;
         for (int c = 0; c < Cin; ++c) {
             float s = 0.f;
+            const float ca = coef ? coef[2 * ((int64_t)n * Cin + c)] : 1.f, cb = coef ? coef[2 * ((int64_t)n * Cin + c) + 1] : 0.f;
+            const float lo = (coef && relu) ? 0.f : -INFINITY;
 #pragma unroll
             for (int u = 0; u < WG_VPT; ++u) {
                 const int64_t e = base + u * 256 + threadIdx.x;
-                if (e < S) s = fmaf(g[u], x[((int64_t)n * Cin + c) * S + e], s);
+                if (e < S) {
+                    float xv = x[((int64_t)n * Cin + c) * S + e];
+                    if (coef) xv = fmaxf(fmaf(ca, xv, cb), lo);
+                    s = fmaf(g[u], xv, s);
+                }
             }
             s = block_sum_256(s, red);
             if (threadIdx.x == 0) prow[c] = s;
@@ -234,23 +249,34 @@ static inline bool vec4_ok(const void* a, const void* b, int64_t S) {
 
 using namespace dram;
 
-extern "C" int dram_conv3d_k1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin,
-                                  int Cout, int64_t S, void* stream) {
-    DRAM_REQUIRE(x && w && y, "conv3d_k1_fwd: null pointer");
-    DRAM_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && S > 0, "conv3d_k1_fwd: bad dimensions");
+static int conv1x1_fwd_run(const char* who, const float* x, const float* coef, int relu, const float* w, const float* bias,
+                           float* y, int N, int Cin, int Cout, int64_t S, void* stream) {
+    DRAM_REQUIRE(x && w && y, "%s: null pointer", who);
+    DRAM_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && S > 0, "%s: bad dimensions", who);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = vec4_ok(x, y, S);
     for (int co0 = 0; co0 < Cout; co0 += MAXCO) {
         const int nco = (Cout - co0) < MAXCO ? (Cout - co0) : MAXCO;
         if (vec) {
             dim3 grid((unsigned)cdiv64(S / 4, 256), N);
-            hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S);
+            hipLaunchKernelGGL(conv1x1_fwd_kernel<true>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S, coef, relu);
         } else {
             dim3 grid((unsigned)cdiv64(S, 256), N);
-            hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S);
+            hipLaunchKernelGGL(conv1x1_fwd_kernel<false>, grid, dim3(256), 0, st, x, w, bias, y, Cin, Cout, co0, nco, S, coef, relu);
         }
     }
-    return check_launch("conv3d_k1_fwd");
+    return check_launch(who);
+}
+
+extern "C" int dram_conv3d_k1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin,
+                                  int Cout, int64_t S, void* stream) {
+    return conv1x1_fwd_run("conv3d_k1_fwd", x, nullptr, 0, w, bias, y, N, Cin, Cout, S, stream);
+}
+
+// 1x1x1 conv of act(coef * x): the norm (+ReLU) of the producing layer applied on load (coef = per-row {a, b})
+extern "C" int dram_conv3d_k1_fwd_lazy(const float* x, const float* coef, int relu, const float* w, const float* bias, float* y,
+                                       int N, int Cin, int Cout, int64_t S, void* stream) {
+    return conv1x1_fwd_run("conv3d_k1_fwd_lazy", x, coef, relu, w, bias, y, N, Cin, Cout, S, stream);
 }
 
 extern "C" size_t dram_conv3d_k1_bwd_ws_bytes(int N, int Cin, int Cout, int64_t S) {
@@ -259,8 +285,8 @@ extern "C" size_t dram_conv3d_k1_bwd_ws_bytes(int N, int Cin, int Cout, int64_t 
     return (size_t)N * nblk * Cout * (Cin + 1) * sizeof(float);
 }
 
-extern "C" int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
-                                  void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S, void* stream) {
+static int conv1x1_bwd_run(const float* dy, const float* x, const float* coef, int relu, const float* w, float* dx, float* dw,
+                           float* dbias, void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S, void* stream) {
     DRAM_REQUIRE(dy && x && w, "conv3d_k1_bwd: null pointer");
     DRAM_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && S > 0, "conv3d_k1_bwd: bad dimensions");
     hipStream_t st = (hipStream_t)stream;
@@ -285,11 +311,23 @@ extern "C" int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* 
         }
         const int nblk = (int)cdiv64(S, WG_VPB);
         float* part = (float*)ws;
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk);
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);
         const int L = Cout * (Cin + 1);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(L), dim3(256), 0, st, part, N * nblk, L, dw, dbias, Cin, Cout);
     }
     return check_launch("conv3d_k1_bwd");
+}
+
+extern "C" int dram_conv3d_k1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                                  void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S, void* stream) {
+    return conv1x1_bwd_run(dy, x, nullptr, 0, w, dx, dw, dbias, ws, ws_bytes, N, Cin, Cout, S, stream);
+}
+
+// backward of dram_conv3d_k1_fwd_lazy: dx is the gradient w.r.t. the ACTIVATED input act(coef * x)
+extern "C" int dram_conv3d_k1_bwd_lazy(const float* dy, const float* x, const float* coef, int relu, const float* w, float* dx,
+                                       float* dw, float* dbias, void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S,
+                                       void* stream) {
+    return conv1x1_bwd_run(dy, x, coef, relu, w, dx, dw, dbias, ws, ws_bytes, N, Cin, Cout, S, stream);
 }
 
 extern "C" size_t dram_channel_sum_ws_bytes(int N, int C, int64_t S) {

@@ -500,6 +500,123 @@ __global__ void bn_pqr_from_sums_kernel(const double* __restrict__ sums, double 
     }
 }
 
+
+// ---- statistics from the conv epilogue (csrc/conv3d_k3.hip stats_epilogue): per (row, part) {mean, M2, count} ----
+// Chan's parallel update of (count, mean, M2) in fp64.
+struct Moments {
+    double n, mean, m2;
+};
+__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    Moments r;
+    r.n = a.n + b.n;
+    const double d = b.mean - a.mean;
+    r.mean = a.mean + d * (b.n / r.n);
+    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+    return r;
+}
+__device__ __forceinline__ Moments wave_merge(Moments m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Moments b;
+        b.n = __shfl_xor(m.n, o, 64);
+        b.mean = __shfl_xor(m.mean, o, 64);
+        b.m2 = __shfl_xor(m.m2, o, 64);
+        // both lanes of a pair must get the same bits: merge in a fixed (low lane, high lane) order
+        const bool low = ((threadIdx.x & 63) & o) == 0;
+        m = low ? chan_merge(m, b) : chan_merge(b, m);
+    }
+    return m;
+}
+// block-wide merge for 256 threads; result valid in thread 0
+__device__ __forceinline__ Moments block_merge_256(Moments m, double* sh /* 12 doubles */) {
+    m = wave_merge(m);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[3 * w] = m.n; sh[3 * w + 1] = m.mean; sh[3 * w + 2] = m.m2; }
+    __syncthreads();
+    Moments r = {sh[0], sh[1], sh[2]};
+#pragma unroll
+    for (int k = 1; k < 4; ++k) r = chan_merge(r, Moments{sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]});
+    return r;
+}
+
+// level 1: grid (groups, rows): group g of a row merges parts [g*per, (g+1)*per) -> part2[(row*groups + g)*3] (doubles)
+constexpr int PARTS_PER_GROUP = 2048;
+__global__ __launch_bounds__(256) void parts_reduce_kernel(const float* __restrict__ part, double* __restrict__ part2,
+                                                           int nparts, int groups) {
+    __shared__ double sh[12];
+    const int64_t row = blockIdx.y;
+    const int g = blockIdx.x;
+    const int beg = g * PARTS_PER_GROUP;
+    const int end = (beg + PARTS_PER_GROUP) < nparts ? (beg + PARTS_PER_GROUP) : nparts;
+    const float* p = part + (row * (int64_t)nparts) * 3;
+    Moments m = {0.0, 0.0, 0.0};
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        const Moments b = {(double)p[3 * (int64_t)i + 2], (double)p[3 * (int64_t)i], (double)p[3 * (int64_t)i + 1]};
+        m = chan_merge(m, b);
+    }
+    m = block_merge_256(m, sh);
+    if (threadIdx.x == 0) {
+        double* o = part2 + (row * groups + g) * 3;
+        o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+    }
+}
+
+// level 2: one block per statistic (as norm_finalize_kernel), members x groups triples
+__global__ __launch_bounds__(256) void norm_finalize_parts_kernel(const double* __restrict__ part2, int groups, int kind, int N,
+                                                                  int C, int G, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                                  float* __restrict__ rowcoef, float* running_mean,
+                                                                  float* running_var, float momentum, double expect_count) {
+    __shared__ double sh[12];
+    __shared__ double bc[3];
+    const int stat = blockIdx.x;
+    const int cpg = C / G;
+    int nmem;
+    int64_t row0, rstride;
+    if (kind == DRAM_NORM_BATCH) { nmem = N; row0 = stat; rstride = C; }
+    else { nmem = cpg; row0 = (int64_t)(stat / G) * C + (int64_t)(stat % G) * cpg; rstride = 1; }
+    const int64_t items = (int64_t)nmem * groups;
+    Moments m = {0.0, 0.0, 0.0};
+    for (int64_t it = threadIdx.x; it < items; it += 256) {
+        const int64_t mem = it / groups;
+        const int g = (int)(it % groups);
+        const double* o = part2 + ((row0 + mem * rstride) * groups + g) * 3;
+        m = chan_merge(m, Moments{o[0], o[1], o[2]});
+    }
+    m = block_merge_256(m, sh);
+    if (threadIdx.x == 0) { bc[0] = m.n; bc[1] = m.mean; bc[2] = m.m2; }
+    __syncthreads();
+    const double total = bc[0] > 0.0 ? bc[0] : 1.0;
+    const double mean = bc[1];
+    const double var = bc[2] / total;  // biased
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    if (threadIdx.x == 0) {
+        // a count that differs from members x spatial size means a partial went missing: poison instead of a silent bias
+        const bool bad = expect_count > 0.0 && bc[0] != expect_count;
+        save_mean[stat] = bad ? NAN : meanf;
+        save_rstd[stat] = bad ? NAN : rstd;
+        if (kind == DRAM_NORM_BATCH && running_mean) {
+            const double unb = total > 1.0 ? bc[2] / (total - 1.0) : var;
+            running_mean[stat] = (1.f - momentum) * running_mean[stat] + momentum * meanf;
+            running_var[stat] = (1.f - momentum) * running_var[stat] + momentum * (float)unb;
+        }
+    }
+    for (int mm = threadIdx.x; mm < nmem; mm += 256) {
+        const int64_t row = row0 + (int64_t)mm * rstride;
+        const int c = (int)(row % C);
+        const float g = gamma ? gamma[c] : 1.f;
+        const float bt = beta ? beta[c] : 0.f;
+        const float a = g * rstd;
+        rowcoef[2 * row] = a;
+        rowcoef[2 * row + 1] = bt - meanf * a;
+    }
+}
+
 static inline bool vec_ok(const void* p, int64_t S) { return (S % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
 static int check_norm(const char* who, int kind, int G, int N, int C, int64_t S) {
@@ -694,6 +811,67 @@ extern "C" int dram_bn_bwd_apply_sums(const float* dy, const float* x, const flo
     else
         hipLaunchKernelGGL(row_bwd_apply_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, dy, x, rowcoef, pqr, dx, S, relu);
     return check_launch("bn_bwd_apply_sums");
+}
+
+
+// ---- statistics that arrive from the conv epilogue ---------------------------------------------------------------
+static inline int parts_groups(int nparts) { return cdiv(nparts, PARTS_PER_GROUP); }
+
+extern "C" size_t dram_norm_parts_ws_bytes(int N, int C, int nparts) {
+    if (N <= 0 || C <= 0 || nparts <= 0) return 0;
+    return (size_t)N * C * parts_groups(nparts) * 3 * sizeof(double);
+}
+
+// Training-mode statistics of BatchNorm / GroupNorm from the {mean, M2, count} partials that the fused convolution
+// left per (row, part) (dram_conv3d_k3_fwd_fused): save_mean / save_rstd per statistic, the per-row {a, b} with
+// y = a*x + b, running statistics updated as dram_norm_fwd_train does.  Nothing reads or writes the tensor itself.
+extern "C" int dram_norm_finalize_parts(const float* parts, int nparts, const float* gamma, const float* beta,
+                                        float* save_mean, float* save_rstd, float* rowcoef, float* running_mean,
+                                        float* running_var, float momentum, float eps, int kind, int G, int N, int C,
+                                        int64_t S, void* ws, size_t ws_bytes, void* stream) {
+    DRAM_REQUIRE(parts && save_mean && save_rstd && rowcoef && ws && nparts > 0, "norm_finalize_parts: null pointer");
+    int rc = check_norm("norm_finalize_parts", kind, G, N, C, S);
+    if (rc) return rc;
+    DRAM_REQUIRE((int64_t)N * C <= 65535, "norm_finalize_parts: N*C > 65535 rows not supported");
+    if (ws_bytes < dram_norm_parts_ws_bytes(N, C, nparts)) {
+        set_error("norm_finalize_parts: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = parts_groups(nparts);
+    double* part2 = (double*)ws;
+    hipLaunchKernelGGL(parts_reduce_kernel, dim3(groups, N * C), dim3(256), 0, st, parts, part2, nparts, groups);
+    const int Gk = kind == DRAM_NORM_BATCH ? 1 : G;
+    const int nstat = kind == DRAM_NORM_BATCH ? C : N * G;
+    const double expect = (double)(kind == DRAM_NORM_BATCH ? N : C / G) * (double)S;
+    hipLaunchKernelGGL(norm_finalize_parts_kernel, dim3(nstat), dim3(256), 0, st, part2, groups, kind, N, C, Gk, gamma, beta,
+                       eps, save_mean, save_rstd, rowcoef, running_mean, running_var, momentum, expect);
+    return check_launch("norm_finalize_parts");
+}
+
+// y = act(rowcoef[row][0] * x + rowcoef[row][1]): materialises a lazily normalised tensor (the consumers without an
+// on-load path, and the fallback of every fused kernel)
+extern "C" int dram_row_affine_act(const float* x, const float* rowcoef, float* y, int relu, int64_t rows, int64_t S,
+                                   void* stream) {
+    DRAM_REQUIRE(x && rowcoef && y && rows > 0 && S > 0, "row_affine_act: bad arguments");
+    DRAM_REQUIRE(rows <= 65535, "row_affine_act: more than 65535 rows not supported");
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(S);
+    if (vec_ok(x, S) && vec_ok(y, S))
+        hipLaunchKernelGGL(row_affine_act_kernel<true>, row_grid(nch, rows), dim3(256), 0, st, x, y, rowcoef, S, relu);
+    else
+        hipLaunchKernelGGL(row_affine_act_kernel<false>, row_grid(nch, rows), dim3(256), 0, st, x, y, rowcoef, S, relu);
+    return check_launch("row_affine_act");
+}
+
+// eval-mode BatchNorm coefficients only (running statistics -> per-row {a, b}; no pass over the tensor)
+extern "C" int dram_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float* save_mean, float* save_rstd, float* rowcoef, float eps, int N, int C, void* stream) {
+    DRAM_REQUIRE(running_mean && running_var && save_mean && save_rstd && rowcoef && N > 0 && C > 0, "bn_eval_coef: bad arguments");
+    const int64_t rows = (int64_t)N * C;
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, N, C, save_mean, save_rstd, rowcoef);
+    return check_launch("bn_eval_coef");
 }
 
 extern "C" int dram_relu_fwd(const float* x, float* y, int64_t n, void* stream) {

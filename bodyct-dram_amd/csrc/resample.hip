@@ -13,21 +13,29 @@ namespace dram {
 // ---------------------------------------------------------------- max pool
 // thread per pooled output; idx = dz*4 + dy*2 + dx of the FIRST maximum in (z,y,x) scan
 // order (ATen: `if (val > maxval || isnan(val))`), which is where the gradient goes.
+// `coef` (optional): x holds the RAW conv output and the pooled tensor is act(a*x + b) per (n,c) row, ReLU if `relu`
+// ("normalise + ReLU on load": the activated tensor is never written; same fmaf / fmaxf as the materialising kernel)
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                            uint8_t* __restrict__ idx, int D, int H, int W, int Do,
-                                                           int Ho, int Wo) {
+                                                           int Ho, int Wo, const float* __restrict__ coef, int relu) {
     const int64_t plane = blockIdx.y;  // n*C + c
     const int So = Do * Ho * Wo;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= So) return;
     const int xo = e % Wo, yo = (e / Wo) % Ho, zo = e / (Wo * Ho);
     const float* p = x + plane * ((int64_t)D * H * W) + ((int64_t)(2 * zo) * H + 2 * yo) * W + 2 * xo;
-    float best = p[0];
+    const float ca = coef ? coef[2 * plane] : 1.f, cb = coef ? coef[2 * plane + 1] : 0.f;
+    const float lo = (coef && relu) ? 0.f : -INFINITY;
+    auto at = [&](int k) {
+        const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+        const float v = p[((int64_t)dz * H + dy) * W + dx];
+        return coef ? fmaxf(fmaf(ca, v, cb), lo) : v;
+    };
+    float best = at(0);
     int bi = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
-        const float v = p[((int64_t)dz * H + dy) * W + dx];
+        const float v = at(k);
         if (v > best || v != v) { best = v; bi = k; }
     }
     out[plane * So + e] = best;
@@ -35,9 +43,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 }
 
 // thread per INPUT element (coalesced dx stores); positions beyond the floor-cropped extent get 0.
+// `accumulate`: dx += (the gradient is added to one that is already there: the skip connection's)
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dout,
-                                                           const uint8_t* __restrict__ idx, float* __restrict__ dx,
-                                                           int D, int H, int W, int Do, int Ho, int Wo) {
+                                                           const uint8_t* __restrict__ idx, float* dx,
+                                                           int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
     const int64_t plane = blockIdx.y;
     const int S = D * H * W;
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -50,14 +59,15 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         const int local = ((zi & 1) << 2) | ((yi & 1) << 1) | (xi & 1);
         if (idx[o] == local) g = dout[o];
     }
+    if (accumulate) g += dx[plane * (int64_t)S + e];
     dx[plane * (int64_t)S + e] = g;
 }
 
 // Same, four consecutive x per thread (W % 4 == 0, so Wo = W/2 and the two pooled cells of a quad are adjacent):
 // one 16-byte store, one 2-byte index load and one 8-byte gradient load instead of 4 + 4 + 4 narrow ones.
 __global__ __launch_bounds__(256) void maxpool2_bwd_vec_kernel(const float* __restrict__ dout,
-                                                               const uint8_t* __restrict__ idx, float* __restrict__ dx,
-                                                               int D, int H, int W, int Do, int Ho, int Wo) {
+                                                               const uint8_t* __restrict__ idx, float* dx,
+                                                               int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
     const int64_t plane = blockIdx.y;
     const int W4 = W >> 2;
     const int S4 = D * H * W4;
@@ -77,7 +87,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_vec_kernel(const float* __re
         g.z = i1 == base ? d.y : 0.f;
         g.w = i1 == (base | 1) ? d.y : 0.f;
     }
-    *reinterpret_cast<float4*>(dx + plane * ((int64_t)D * H * W) + 4 * (int64_t)e) = g;
+    float4* q = reinterpret_cast<float4*>(dx + plane * ((int64_t)D * H * W) + 4 * (int64_t)e);
+    if (accumulate) {
+        const float4 old = *q;
+        g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+    }
+    *q = g;
 }
 
 // ---------------------------------------------------------------- trilinear, align_corners=True
@@ -103,7 +118,8 @@ __device__ __forceinline__ void src_index(const Axis& a, int o, int& i0, int& i1
 // consecutive (n,c) planes (the index arithmetic, not the 8 loads, dominates a plane-per-thread version)
 constexpr int TRI_CPT = 8;
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            Axis az, Axis ay, Axis ax, int planes) {
+                                                            Axis az, Axis ay, Axis ax, int planes,
+                                                            const float* __restrict__ coef, int relu) {
     const int So = az.out * ay.out * ax.out;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= So) return;
@@ -125,8 +141,14 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
         const int plane = p0 + u;
         if (plane >= planes) break;
         const float* p = x + (int64_t)plane * Si;
-        const float v = a0 * (b0 * (c0 * p[o000] + c1 * p[o001]) + b1 * (c0 * p[o010] + c1 * p[o011])) +
-                        a1 * (b0 * (c0 * p[o100] + c1 * p[o101]) + b1 * (c0 * p[o110] + c1 * p[o111]));
+        float t[8] = {p[o000], p[o001], p[o010], p[o011], p[o100], p[o101], p[o110], p[o111]};
+        if (coef) {   // the source is a RAW conv output: interpolate act(a*x + b) (normalise + ReLU on load)
+            const float ca = coef[2 * plane], cb = coef[2 * plane + 1], lo = relu ? 0.f : -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = fmaxf(fmaf(ca, t[k], cb), lo);
+        }
+        const float v = a0 * (b0 * (c0 * t[0] + c1 * t[1]) + b1 * (c0 * t[2] + c1 * t[3])) +
+                        a1 * (b0 * (c0 * t[4] + c1 * t[5]) + b1 * (c0 * t[6] + c1 * t[7]));
         y[(int64_t)plane * So + e] = v;
     }
 }
@@ -389,26 +411,52 @@ extern "C" int dram_maxpool3d_2_fwd(const float* x, float* out, uint8_t* idx, in
     if (rc) return rc;
     const int Do = D / 2, Ho = H / 2, Wo = W / 2;
     dim3 grid(cdiv(Do * Ho * Wo, 256), N * C);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, idx, D, H, W, Do, Ho, Wo);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, idx, D, H, W, Do, Ho, Wo,
+                       (const float*)nullptr, 0);
     return check_launch("maxpool3d_2_fwd");
 }
 
-extern "C" int dram_maxpool3d_2_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
-                                    int W, void* stream) {
-    DRAM_REQUIRE(dout && idx && dx, "maxpool3d_2_bwd: null pointer");
-    DRAM_REQUIRE(D >= 2 && H >= 2 && W >= 2, "maxpool3d_2_bwd: spatial size below the 2x2x2 window");
-    int rc = check_planes("maxpool3d_2_bwd", (int64_t)N * C, (int64_t)D * H * W);
+// max_pool3d(act(coef * x)) with the norm (+ReLU) applied on load; coef = per-row {a, b} (null: plain input)
+extern "C" int dram_maxpool3d_2_fwd_lazy(const float* x, const float* coef, int relu, float* out, uint8_t* idx, int N, int C,
+                                         int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(x && out && idx, "maxpool3d_2_fwd_lazy: null pointer");
+    DRAM_REQUIRE(D >= 2 && H >= 2 && W >= 2, "maxpool3d_2_fwd_lazy: spatial size below the 2x2x2 window");
+    int rc = check_planes("maxpool3d_2_fwd_lazy", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    dim3 grid(cdiv(Do * Ho * Wo, 256), N * C);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, idx, D, H, W, Do, Ho, Wo, coef,
+                       relu);
+    return check_launch("maxpool3d_2_fwd_lazy");
+}
+
+static int maxpool_bwd_run(const char* who, const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
+                           int W, int accumulate, void* stream) {
+    DRAM_REQUIRE(dout && idx && dx, "%s: null pointer", who);
+    DRAM_REQUIRE(D >= 2 && H >= 2 && W >= 2, "%s: spatial size below the 2x2x2 window", who);
+    int rc = check_planes(who, (int64_t)N * C, (int64_t)D * H * W);
     if (rc) return rc;
     if (W % 4 == 0 && ((((uintptr_t)dout) & 7) | (((uintptr_t)idx) & 1) | (((uintptr_t)dx) & 15)) == 0) {
         dim3 grid(cdiv(D * H * (W / 4), 256), N * C);
         hipLaunchKernelGGL(maxpool2_bwd_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, idx, dx, D, H, W,
-                           D / 2, H / 2, W / 2);
+                           D / 2, H / 2, W / 2, accumulate);
     } else {
         dim3 grid(cdiv(D * H * W, 256), N * C);
         hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, idx, dx, D, H, W, D / 2,
-                           H / 2, W / 2);
+                           H / 2, W / 2, accumulate);
     }
-    return check_launch("maxpool3d_2_bwd");
+    return check_launch(who);
+}
+
+extern "C" int dram_maxpool3d_2_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
+                                    int W, void* stream) {
+    return maxpool_bwd_run("maxpool3d_2_bwd", dout, idx, dx, N, C, D, H, W, 0, stream);
+}
+
+// dx += scatter(dout): the pooled branch's gradient added onto the skip branch's, in one pass
+extern "C" int dram_maxpool3d_2_bwd_acc(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
+                                        int W, void* stream) {
+    return maxpool_bwd_run("maxpool3d_2_bwd_acc", dout, idx, dx, N, C, D, H, W, 1, stream);
 }
 
 extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, int C, int D, int H, int W, int Do,
@@ -419,8 +467,21 @@ extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, i
     if (rc) return rc;
     dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
     hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
-                       make_axis(H, Ho), make_axis(W, Wo), N * C);
+                       make_axis(H, Ho), make_axis(W, Wo), N * C, (const float*)nullptr, 0);
     return check_launch("upsample_trilinear_ac_fwd");
+}
+
+// upsample(act(coef * x)) with the norm (+ReLU) applied on load; coef = per-row {a, b} (null: plain input)
+extern "C" int dram_upsample_trilinear_ac_fwd_lazy(const float* x, const float* coef, int relu, float* y, int N, int C, int D,
+                                                   int H, int W, int Do, int Ho, int Wo, void* stream) {
+    DRAM_REQUIRE(x && y, "upsample_trilinear_ac_fwd_lazy: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_fwd_lazy: bad sizes");
+    int rc = check_planes("upsample_trilinear_ac_fwd_lazy", (int64_t)N * C, (int64_t)Do * Ho * Wo);
+    if (rc) return rc;
+    dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
+    hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
+                       make_axis(H, Ho), make_axis(W, Wo), N * C, coef, relu);
+    return check_launch("upsample_trilinear_ac_fwd_lazy");
 }
 
 // Two-stage backward (z first, then y/x) through a caller-provided workspace; planes are processed in groups
@@ -527,7 +588,7 @@ extern "C" int dram_resize_trilinear_fwd(const float* x, float* y, int N, int C,
     if (rc) return rc;
     dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
     hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis_half(D, Do, scale_z),
-                       make_axis_half(H, Ho, scale_y), make_axis_half(W, Wo, scale_x), N * C);
+                       make_axis_half(H, Ho, scale_y), make_axis_half(W, Wo, scale_x), N * C, (const float*)nullptr, 0);
     return check_launch("resize_trilinear_fwd");
 }
 

@@ -77,6 +77,20 @@ SIGNATURES = {
     "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_bwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, P]),
+    # fused conv -> norm -> ReLU -> conv chains ("lazy" tensors)
+    "dram_conv3d_k3_stats_parts": (I, [I, I, I, I, I]),
+    "dram_conv3d_k3_fwd_fused": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, P, I, I, I, I, I, I, P]),
+    "dram_conv3d_k3_wgrad_lazy_ok": (I, [I, I, I, I, I, I, I]),
+    "dram_conv3d_k3_wgrad_fused": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, Z, I, I, I, I, I, P]),
+    "dram_norm_parts_ws_bytes": (Z, [I, I, I]),
+    "dram_norm_finalize_parts": (I, [P, I, P, P, P, P, P, P, P, F, F, I, I, I, I, L, P, Z, P]),
+    "dram_bn_eval_coef": (I, [P, P, P, P, P, P, P, F, I, I, P]),
+    "dram_row_affine_act": (I, [P, P, P, I, L, L, P]),
+    "dram_maxpool3d_2_fwd_lazy": (I, [P, P, I, P, P, I, I, I, I, I, P]),
+    "dram_maxpool3d_2_bwd_acc": (I, [P, P, P, I, I, I, I, I, P]),
+    "dram_upsample_trilinear_ac_fwd_lazy": (I, [P, P, I, P, I, I, I, I, I, I, I, I, P]),
+    "dram_conv3d_k1_fwd_lazy": (I, [P, P, I, P, P, P, I, I, I, L, P]),
+    "dram_conv3d_k1_bwd_lazy": (I, [P, P, P, I, P, P, P, P, P, Z, I, I, I, L, P]),
 }
 
 

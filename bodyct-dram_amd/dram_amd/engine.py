@@ -1,0 +1,437 @@
+"""Fused execution of DC3D's conv -> norm -> ReLU chains.
+
+The per-op path (`functional.py`, one autograd Function per ATen op of the reference) writes, for every
+conv -> norm -> ReLU stage (reference dram/parts.py:177-187), the raw conv output, reads it for the norm
+statistics, and reads it again to write the activated tensor that the next layer consumes -- and keeps both
+tensors for backward.  Here the whole network (reference dram/models.py:120-147) is ONE autograd Function whose
+forward and backward are explicit sequences of C-ABI calls over "lazy" tensors:
+
+  * a conv writes its raw output y once; its epilogue leaves the BatchNorm / GroupNorm moments of y as partials
+    (`dram_conv3d_k3_fwd_fused`), `dram_norm_finalize_parts` turns them into per-row coefficients {a, b};
+  * the activated tensor act(a*y + b) is never written: every consumer -- the next conv (forward and
+    backward-weights), the max-pool, the trilinear upsample, the 1x1x1 head -- applies it while loading;
+  * backward keeps the reference's arithmetic (norm backward = two reductions + one apply, in place on the
+    incoming gradient; conv backward-data / backward-weights on the matrix cores) and recomputes the upsampled
+    tensor of an UpsampleConvBlock5d for its backward-weights instead of keeping it.
+
+Saved for backward per stage: the raw output and {a, b, mean, rstd} -- about 0.4x of what the per-op path keeps
+(DESIGN.md section 5), with values bit-identical to that path's (same fmaf / fmaxf on the same inputs).
+
+Not an oracle and not a fallback: every step is a kernel of libdram_hip.so.  Networks the engine does not cover
+(SyncBatchNorm, PReLU, dropout, `lite` blocks, conv kernels other than 3x3x3, checkpoint_mode="recompute") run the
+per-op path.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from . import functional as HF
+from ._lib import call
+from .functional import NORM_BATCH, NORM_GROUP, _p, _stream, _ws, crop_offsets
+from .modules import HipBatchNorm3d, HipConv3d, HipGroupNorm, HipMaxPool3d, HipReLU, HipSyncBatchNorm, HipUpsample
+
+
+class Lazy:
+    """The tensor act(coef[row][0] * raw + coef[row][1]) (ReLU if relu), or `raw` itself when coef is None."""
+    __slots__ = ("raw", "coef", "relu")
+
+    def __init__(self, raw, coef=None, relu=False):
+        self.raw, self.coef, self.relu = raw, coef, bool(relu)
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def materialise(self):
+        if self.coef is None:
+            return self.raw
+        N, C = self.raw.shape[:2]
+        S = self.raw.numel() // (N * C)
+        y = torch.empty_like(self.raw)
+        call("dram_row_affine_act", _p(self.raw), _p(self.coef), _p(y), int(self.relu), N * C, S, _stream())
+        return y
+
+
+class Upsampled:
+    """The x`scale` trilinear (align_corners=True) upsampling of a Lazy, as a recipe: produced when needed, not kept."""
+    __slots__ = ("src", "size")
+
+    def __init__(self, src, size):
+        self.src, self.size = src, tuple(int(v) for v in size)
+
+    def produce(self):
+        N, C, D, H, W = self.src.raw.shape
+        y = torch.empty((N, C) + self.size, dtype=torch.float32, device=self.src.raw.device)
+        call("dram_upsample_trilinear_ac_fwd_lazy", _p(self.src.raw), _p(self.src.coef), int(self.src.relu), _p(y), N, C,
+             D, H, W, *self.size, _stream())
+        return y
+
+
+# ------------------------------------------------------------------------------------------------ applicability
+def _stage_modules(seq):
+    """[conv, norm, relu] of one entry of `conv_blocks` (parts.py:102-110), or None if the stage is anything else."""
+    mods = list(seq)
+    if len(mods) != 3:
+        return None
+    conv, norm, act = mods
+    if not isinstance(conv, HipConv3d) or conv.kernel_size != (3, 3, 3) or conv.padding != (1, 1, 1) \
+            or conv.stride != (1, 1, 1) or conv.dilation != (1, 1, 1) or conv.groups != 1 or conv.bias is not None:
+        return None
+    if isinstance(norm, HipSyncBatchNorm) or not isinstance(norm, (HipBatchNorm3d, HipGroupNorm)):
+        return None
+    if not isinstance(act, HipReLU):
+        return None
+    return conv, norm, act
+
+
+def supports(model):
+    """True if `model` (a models.DC3D) is made of the standard blocks only."""
+    try:
+        blocks = list(model.ds_modules) + [model.bg] + (list(model.us_modules) if model.us_modules is not None else [])
+        for blk in blocks:
+            if any(_stage_modules(seq) is None for seq in blk.conv_blocks):
+                return False
+        for ds in model.ds_modules:
+            if not isinstance(ds.maxpool, HipMaxPool3d):
+                return False
+        for us in (model.us_modules or []):
+            if not isinstance(us.upsample, HipUpsample) or us.upsample.mode != "trilinear" or not us.upsample.align_corners:
+                return False
+        top = model.top_layer
+        return isinstance(top, HipConv3d) and top.kernel_size == (1, 1, 1) and top.padding == (0, 0, 0)
+    except AttributeError:
+        return False
+
+
+def parameters_of(model):
+    """The parameters the engine differentiates, in a fixed order (the autograd Function's tensor inputs)."""
+    return [p for p in model.parameters()]
+
+
+# ------------------------------------------------------------------------------------------------ forward pieces
+class _Stage:
+    """What backward needs of one conv -> norm -> ReLU stage."""
+    __slots__ = ("conv", "norm", "inp", "skip", "geom", "y", "coef", "mean", "rstd", "kind", "groups", "batch_stats",
+                 "out", "need_input_grad")
+
+
+def _norm_plan(norm, training):
+    """(kind, groups, use_batch_stats, running_mean, running_var, exponential average factor): the bookkeeping of
+    HipBatchNorm3d.forward / HipGroupNorm.forward (torch.nn.modules.batchnorm._BatchNorm.forward)."""
+    if isinstance(norm, HipGroupNorm):
+        return NORM_GROUP, norm.num_groups, True, None, None, 0.0
+    use_batch, eaf, rm, rv = norm.bookkeeping()
+    return NORM_BATCH, 1, use_batch, rm, rv, eaf
+
+
+def _conv_stage(conv, norm, inp, skip, training, record):
+    """y = conv(inp ++ crop(skip)) with the moments of y from the epilogue -> Lazy(y, coef, relu).  `inp` is a Lazy or
+    an Upsampled recipe (then produced here, used, and dropped)."""
+    src = inp.produce() if isinstance(inp, Upsampled) else None
+    x1 = Lazy(src) if src is not None else inp
+    N, C1, D, H, W = x1.raw.shape
+    w = conv.weight
+    Co, Ci = w.shape[0], w.shape[1]
+    dev = w.device
+    if skip is not None:
+        C2, D2, H2, W2 = skip.raw.shape[1:]
+        if skip.raw.shape[0] != N or not (D <= D2 and H <= H2 and W <= W2):
+            raise ValueError("fused conv stage: the skip tensor must have the same batch and be at least as large")
+        oz, oy, ox = crop_offsets((D, H, W), (D2, H2, W2))
+    else:
+        C2 = D2 = H2 = W2 = oz = oy = ox = 0
+    if C1 + C2 != Ci:
+        raise ValueError(f"fused conv stage: input has {C1 + C2} channels, weight expects {Ci}")
+    kind, groups, use_batch, rm, rv, eaf = _norm_plan(norm, training)
+    S = D * H * W
+    st = _stream()
+    wt = HF._pack(w, 0)
+    y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=dev)
+    nstat = Co if kind == NORM_BATCH else N * groups
+    mean = torch.empty(nstat, dtype=torch.float32, device=dev)
+    rstd = torch.empty(nstat, dtype=torch.float32, device=dev)
+    coef = torch.empty(2 * N * Co, dtype=torch.float32, device=dev)
+    gamma, beta = norm.weight, norm.bias
+    vox = N * S
+    name = HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True)
+    if use_batch:
+        nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W)
+        parts = torch.empty(N * Co * nparts * 3, dtype=torch.float32, device=dev)
+        HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                       "dram_conv3d_k3_fwd_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
+                       _p(skip.raw) if skip is not None else None, C2, _p(skip.coef) if skip is not None else None,
+                       int(skip.relu) if skip is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y), _p(parts),
+                       nparts, N, Co, D, H, W, st)
+        ws = _ws(_lib.lib.dram_norm_parts_ws_bytes(N, Co, nparts), dev)
+        call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef), _p(rm), _p(rv),
+             float(eaf), float(norm.eps), kind, groups, N, Co, S, _p(ws), ws.numel(), st)
+    else:   # eval-mode BatchNorm: coefficients from the running statistics
+        HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                       "dram_conv3d_k3_fwd_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
+                       _p(skip.raw) if skip is not None else None, C2, _p(skip.coef) if skip is not None else None,
+                       int(skip.relu) if skip is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y), None,
+                       0, N, Co, D, H, W, st)
+        call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
+    out = Lazy(y, coef, relu=True)
+    if record is not None:
+        s = _Stage()
+        s.conv, s.norm, s.inp, s.skip = conv, norm, inp, skip
+        s.geom = (C1, C2, D2, H2, W2, oz, oy, ox)
+        s.y, s.coef, s.mean, s.rstd = y, coef, mean, rstd
+        s.kind, s.groups, s.batch_stats, s.out = kind, groups, bool(use_batch), out
+        record.append(("conv", s))
+    return out
+
+
+def _conv_stack(conv_blocks, inp, skip, training, record):
+    cur = inp
+    for j, seq in enumerate(conv_blocks):
+        conv, norm, _ = _stage_modules(seq)
+        cur = _conv_stage(conv, norm, cur, skip if j == 0 else None, training, record)
+    return cur
+
+
+def _pool(lz, record):
+    N, C, D, H, W = lz.raw.shape
+    out = torch.empty((N, C, D // 2, H // 2, W // 2), dtype=torch.float32, device=lz.raw.device)
+    idx = torch.empty(out.shape, dtype=torch.uint8, device=lz.raw.device)
+    call("dram_maxpool3d_2_fwd_lazy", _p(lz.raw), _p(lz.coef), int(lz.relu), _p(out), _p(idx), N, C, D, H, W, _stream())
+    res = Lazy(out)
+    if record is not None:
+        record.append(("pool", lz, idx, res))
+    return res
+
+
+def _bn_modules(block):
+    return [m for m in block.modules() if isinstance(m, nn.BatchNorm3d)]
+
+
+def forward(model, x, record):
+    """DC3D.forward (models.py:120-147) on lazy tensors.  `record`: list that receives the tape for backward, or None
+    (inference).  Returns the dense output [N, out_ch, D, H, W]."""
+    training = model.training
+    L = model.n_layers
+    x = HF._chk(x, "DC3D input", 5)
+    grad_flows = record is not None          # the reference re-runs a checkpointed block in backward only then
+    cur = Lazy(x)
+    if record is not None:
+        record.append(("input", cur))
+    skips = []
+
+    def run_block(flag, block, fn):
+        # `checkpoint_layers` in 'stats' mode: a flagged block's BatchNorm running statistics absorb the batch twice
+        # (models.DC3D._run)
+        twice = flag > 0 and training and grad_flows
+        norms = _bn_modules(block) if twice else []
+        for m in norms:
+            m.stat_updates = 2
+        try:
+            return fn()
+        finally:
+            for m in norms:
+                m.stat_updates = 1
+
+    for i, ds in enumerate(model.ds_modules):
+        feat = run_block(model.checkpoint_layers[i], ds, lambda: _conv_stack(ds.conv_blocks, cur, None, training, record))
+        skips.append(feat)
+        cur = _pool(feat, record)
+    cur = run_block(model.checkpoint_layers[L], model.bg, lambda: _conv_stack(model.bg.conv_blocks, cur, None, training, record))
+    if model.us_modules is not None:
+        for i, (us, skip) in enumerate(zip(model.us_modules, reversed(skips))):
+            if model.stacking == i:
+                break
+            D, H, W = cur.raw.shape[2:]
+            sf = us.scale_factor if isinstance(us.scale_factor, (tuple, list)) else (us.scale_factor,) * 3
+            size = tuple(int(float(d) * float(s)) for d, s in zip((D, H, W), sf))   # torch: floor(input * scale_factor)
+            if not (size[2] <= skip.raw.shape[-1]):
+                raise AssertionError("UpsampleConvBlock5d: upsampled tensor larger than the skip tensor")
+            up = Upsampled(cur, size)
+            if record is not None:
+                record.append(("up", cur, size))
+            # NB: the flag index is n_layers + idx, not n_layers + 1 + idx (models.py:140)
+            cur = run_block(model.checkpoint_layers[L + i], us, lambda: _conv_stack(us.conv_blocks, up, skip, training, record))
+    top = model.top_layer
+    N, C, D, H, W = cur.raw.shape
+    Co = top.weight.shape[0]
+    dense = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x.device)
+    call("dram_conv3d_k1_fwd_lazy", _p(cur.raw), _p(cur.coef), int(cur.relu), _p(top.weight), _p(top.bias), _p(dense),
+         N, C, Co, D * H * W, _stream())
+    if record is not None:
+        record.append(("head", cur))
+    if tuple(dense.shape[-3:]) != tuple(x.shape[-3:]):
+        small = dense
+        dense = torch.empty((N, Co) + tuple(x.shape[-3:]), dtype=torch.float32, device=x.device)
+        call("dram_upsample_trilinear_ac_fwd", _p(small), _p(dense), N, Co, D, H, W, *x.shape[-3:], _stream())
+        if record is not None:
+            record.append(("resize", tuple(small.shape)))
+    return dense
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def _trilinear_bwd(dy, in_shape):
+    N, C, D, H, W = in_shape
+    Do, Ho, Wo = dy.shape[-3:]
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    full = _lib.lib.dram_upsample_trilinear_ac_bwd_ws_bytes(N, C, D, H, W, Do, Ho, Wo)
+    ws = _ws(min(full, HF.TRI_BWD_WS_CAP), dy.device) if full else None
+    call("dram_upsample_trilinear_ac_bwd_ws", _p(dy), _p(dx), _p(ws), ws.numel() if ws is not None else 0,
+         N, C, D, H, W, Do, Ho, Wo, _stream())
+    return dx
+
+
+def backward(model, record, gout, need_dx):
+    """Returns ({parameter: gradient}, dx or None).  `gout`: gradient w.r.t. the dense output."""
+    st = _stream()
+    grads = {}          # parameter -> gradient
+    gact = {}           # id(Lazy) -> dense gradient w.r.t. the ACTIVATED tensor (accumulated over its consumers)
+    g = HF._chk(gout, "DC3D grad_output", 5)
+    root = record[0][1]
+    for item in reversed(record):
+        tag = item[0]
+        if tag == "input":
+            continue
+        if tag == "resize":
+            g = _trilinear_bwd(g, item[1])
+        elif tag == "head":
+            lz = item[1]
+            top = model.top_layer
+            N, C, D, H, W = lz.raw.shape
+            Co, S = top.weight.shape[0], D * H * W
+            dxa = torch.empty_like(lz.raw)
+            dw = torch.empty_like(top.weight)
+            db = torch.empty(Co, dtype=torch.float32, device=g.device) if top.bias is not None else None
+            ws = _ws(_lib.lib.dram_conv3d_k1_bwd_ws_bytes(N, C, Co, S), g.device)
+            call("dram_conv3d_k1_bwd_lazy", _p(g), _p(lz.raw), _p(lz.coef), int(lz.relu), _p(top.weight), _p(dxa), _p(dw),
+                 _p(db), _p(ws), ws.numel(), N, C, Co, S, st)
+            grads[top.weight] = dw
+            if db is not None:
+                grads[top.bias] = db
+            gact[id(lz)] = dxa
+            g = None
+        elif tag == "conv":
+            s = item[1]
+            g = gact.pop(id(s.out))
+            N, Co, D, H, W = s.y.shape
+            S = D * H * W
+            C1, C2, D2, H2, W2, oz, oy, ox = s.geom
+            Ci = C1 + C2
+            w = s.conv.weight
+            # norm (+ReLU) backward, in place: g <- d(raw conv output)
+            gamma = s.norm.weight
+            dgamma = torch.empty(Co, dtype=torch.float32, device=g.device) if gamma is not None else None
+            dbeta = torch.empty(Co, dtype=torch.float32, device=g.device) if s.norm.bias is not None else None
+            ws = _ws(_lib.lib.dram_norm_ws_bytes(N, Co, S), g.device)
+            call("dram_norm_bwd", _p(g), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(g), _p(dgamma), _p(dbeta),
+                 s.kind, s.groups, 1, int(s.batch_stats), N, Co, S, _p(ws), ws.numel(), st)
+            if dgamma is not None:
+                grads[gamma] = dgamma
+            if dbeta is not None:
+                grads[s.norm.bias] = dbeta
+            vox = N * S
+            # backward-weights: the x operand is the stage's lazy input(s); an upsampled input is produced again
+            inp = s.inp
+            up_tmp = inp.produce() if isinstance(inp, Upsampled) else None
+            x1 = Lazy(up_tmp) if up_tmp is not None else inp
+            skip = s.skip
+            dw = torch.empty_like(w)
+            wsb = _ws(_lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W), g.device)
+            name = HF.conv_wgrad_kernel_name((D, H, W), Co, Ci if skip is None else None,
+                                             lazy=(x1.coef is not None or (skip is not None and skip.coef is not None)))
+            lazy_ok = bool(_lib.lib.dram_conv3d_k3_wgrad_lazy_ok(N, C1, C2, Co, D, H, W))
+            if not lazy_ok:     # kernels without the on-load path (odd widths, first layer): plain operands
+                x1 = Lazy(x1.materialise())
+                skip_w = Lazy(skip.materialise()) if skip is not None else None
+            else:
+                skip_w = skip
+            HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                           "dram_conv3d_k3_wgrad_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
+                           _p(skip_w.raw) if skip_w is not None else None, C2,
+                           _p(skip_w.coef) if skip_w is not None else None, int(skip_w.relu) if skip_w is not None else 0,
+                           D2, H2, W2, oz, oy, ox, _p(g), _p(dw), _p(wsb), wsb.numel(), N, Co, D, H, W, st)
+            grads[w] = dw
+            del up_tmp, x1, skip_w
+            # backward-data: gradient w.r.t. the activated input(s)
+            is_root = (not isinstance(inp, Upsampled)) and inp is root
+            if skip is not None or not is_root or need_dx:
+                wt = HF._pack(w, 1)
+                dx1 = torch.empty((N, C1, D, H, W), dtype=torch.float32, device=g.device)
+                dx2 = None
+                if skip is not None:
+                    if id(skip) in gact:
+                        raise RuntimeError("fused backward: a skip tensor received a gradient before its up-path consumer")
+                    full = (D2, H2, W2) == (D, H, W)
+                    dx2 = torch.empty_like(skip.raw) if full else torch.zeros_like(skip.raw)
+                HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                               "dram_conv3d_k3_fwd_ex", _p(g), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
+                               _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
+                if skip is not None:
+                    gact[id(skip)] = dx2
+                if isinstance(inp, Upsampled):
+                    gact[("up", id(inp.src))] = dx1
+                else:
+                    _accumulate(gact, id(inp), dx1)
+            g = None
+        elif tag == "up":
+            lz, size = item[1], item[2]
+            gup = gact.pop(("up", id(lz)))
+            _accumulate(gact, id(lz), _trilinear_bwd(gup, tuple(lz.raw.shape)))
+        elif tag == "pool":
+            lz, idx, res = item[1], item[2], item[3]
+            gp = gact.pop(id(res), None)
+            if gp is None:
+                continue
+            N, C, D, H, W = lz.raw.shape
+            if id(lz) in gact:      # the skip branch's gradient is already there: add the pooled branch's onto it
+                call("dram_maxpool3d_2_bwd_acc", _p(gp), _p(idx), _p(gact[id(lz)]), N, C, D, H, W, st)
+            else:
+                dxp = torch.empty_like(lz.raw)
+                call("dram_maxpool3d_2_bwd", _p(gp), _p(idx), _p(dxp), N, C, D, H, W, st)
+                gact[id(lz)] = dxp
+        else:   # pragma: no cover
+            raise RuntimeError(f"fused backward: unknown tape entry {tag!r}")
+    return grads, gact.pop(id(root), None)
+
+
+def _accumulate(gact, key, t):
+    if key in gact:
+        gact[key].add_(t)
+    else:
+        gact[key] = t
+
+
+# ------------------------------------------------------------------------------------------------ autograd wrapper
+class DC3DFusedFn(Function):
+    """dense = DC3D(x) through the fused engine; differentiable w.r.t. x and every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        # (torch runs Function.forward under no_grad: whether a gradient is wanted comes from needs_input_grad)
+        record = [] if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[2:]) else None
+        out = forward(model, x, record)
+        ctx.model, ctx.record, ctx.params = model, record, params
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        model, record, params = ctx.model, ctx.record, ctx.params
+        if record is None:
+            raise RuntimeError("DC3DFusedFn: backward without a recorded forward")
+        try:
+            grads, dx = backward(model, record, gout, ctx.needs_input_grad[1])
+        finally:
+            ctx.record = None        # free the saved activations now, not when the graph dies
+        out = [None, dx if ctx.needs_input_grad[1] else None]
+        for p, need in zip(params, ctx.needs_input_grad[2:]):
+            out.append(grads.get(p) if need else None)
+        return tuple(out)
+
+
+def run(model, x):
+    """DC3D forward through the engine (autograd-connected when gradients are enabled)."""
+    params = parameters_of(model)
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return DC3DFusedFn.apply(model, x, *params)
+    return forward(model, x, None)

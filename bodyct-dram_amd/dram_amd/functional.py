@@ -63,24 +63,25 @@ def _pick_box(dhw, boxes):
     return min(boxes, key=vol)
 
 
-def conv_fwd_kernel_name(dhw, Cout, Cin):
+def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False):
     """Name of the forward / backward-data kernel instantiation the library picks (csrc/conv3d_k3.hip
-    conv_fwd_dispatch), as rocprofv3 prints it."""
+    fwd_choice), as rocprofv3 prints it.  `fused`: the variant with lazy operands / the statistics epilogue."""
     cot = 1 if Cout <= 32 else 2
+    flag = "true" if fused else "false"
     if Cin >= 8 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):
         box = min([(32, 4), (16, 8), (8, 16), (10, 10)], key=lambda b: -(-dhw[2] // b[0]) * -(-dhw[1] // b[1]))
-        return f"conv3d_k3_fwd_wz_kernel<{box[0]}, {box[1]}, {cot}>"
+        return f"conv3d_k3_fwd_wz_kernel<{box[0]}, {box[1]}, {cot}, {flag}>"
     box = _pick_box(dhw, [(32, 4, 2), (16, 4, 4), (8, 8, 4)])
-    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {cot}>"
+    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {cot}, {flag}>"
 
 
-def conv_wgrad_kernel_name(dhw, Cout, Cin=None):
+def conv_wgrad_kernel_name(dhw, Cout, Cin=None, lazy=False):
     if Cin == 1:
         return "conv3d_k3_wgrad_c1_kernel"
     tile = '8, 1' if Cout > 64 else '4, 2'
     if dhw[2] % 4 == 0 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):   # csrc/conv3d_k3.hip wgrad_plan
         bx = 16 if dhw[2] % 16 == 0 else (8 if dhw[2] % 8 == 0 else 4)
-        return f"conv3d_k3_wgrad_wz_kernel<{bx}, {32 // bx}, {tile}>"
+        return f"conv3d_k3_wgrad_wz_kernel<{bx}, {32 // bx}, {tile}, {'true' if lazy else 'false'}>"
     box = _pick_box(dhw, [(16, 2, 2), (32, 2, 1), (8, 4, 2)])
     kind = "wgrad_vec" if dhw[2] % box[0] == 0 else "wgrad"       # 16-byte staging needs full boxes along x
     return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {tile}>"

@@ -45,10 +45,10 @@ class HipBatchNorm3d(nn.BatchNorm3d, _NormMixin):
     # reference would run twice per step through torch.utils.checkpoint; models.DC3D._run)
     stat_updates = 1
 
-    def forward(self, x, relu=False):
-        self._check_input_dim(x)
-        # same bookkeeping as torch.nn.modules.batchnorm._BatchNorm.forward, repeated stat_updates
-        # times with the same batch statistics: r <- (1-m) r + m b twice == once with 1-(1-m)^2
+    def bookkeeping(self):
+        """The per-call bookkeeping of torch.nn.modules.batchnorm._BatchNorm.forward, repeated stat_updates times with
+        the same batch statistics (r <- (1-m) r + m b twice == once with 1-(1-m)^2).  Increments num_batches_tracked.
+        Returns (use_batch_stats, exponential_average_factor, running_mean, running_var)."""
         eaf = 0.0 if self.momentum is None else self.momentum
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             keep = 1.0
@@ -60,6 +60,11 @@ class HipBatchNorm3d(nn.BatchNorm3d, _NormMixin):
         use_batch = self.training or (self.running_mean is None and self.running_var is None)
         rm = self.running_mean if (not self.training or self.track_running_stats) else None
         rv = self.running_var if (not self.training or self.track_running_stats) else None
+        return use_batch, eaf, rm, rv
+
+    def forward(self, x, relu=False):
+        self._check_input_dim(x)
+        use_batch, eaf, rm, rv = self.bookkeeping()
         return HF.norm_act(x, self.weight, self.bias, rm, rv, HF.NORM_BATCH, 1, use_batch, eaf, self.eps, relu)
 
 

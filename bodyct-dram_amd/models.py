@@ -19,6 +19,7 @@ Reference citations are to /root/reference/dram/models.py.
 from parts import *  # noqa: F401,F403  (the reference relies on this star import, models.py:5)
 from parts import ConvBlock5d, ConvPoolBlock5d, Identity, UpsampleConvBlock5d, checkpoint, functools, nn, np, torch
 
+from dram_amd import engine as _engine
 from dram_amd import functional as HF
 from dram_amd.modules import HipBatchNorm3d, HipConv3d, HipReLU, HipUpsample, run_conv_stack
 
@@ -166,7 +167,16 @@ class DC3D(nn.Module):
             for m in norms:
                 m.stat_updates = 1
 
+    # `fused` (default): the forward/backward of a standard network (every stage conv3x3x3 -> BatchNorm/GroupNorm ->
+    # ReLU) runs through dram_amd/engine.py: norm statistics in the conv epilogue, normalise + ReLU applied on load by
+    # every consumer, one autograd node for the whole network.  Other networks, checkpoint_mode="recompute" and
+    # fused=False take the per-op path below (one autograd Function per op of the reference).  Same values either way.
+    fused = True
+
     def forward(self, x, lungs=None):
+        if self.fused and self.checkpoint_mode != "recompute" and _engine.supports(self):
+            dense_outs = _engine.run(self, x)
+            return dense_outs, dense_outs
         L = self.n_layers
         skips = []
         cur = x

@@ -294,6 +294,72 @@ int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets
 int dram_pcm_aggregate_bwd(const float* attn, const float* v, const float* dout, const int* offsets, int E,
                            float* dattn, float* dv, int B, int C, int D, int H, int W, void* stream);
 
+/* ---- fused conv -> norm -> ReLU -> conv chains (parts.py:177-187 conv -> norm -> act) ----
+ *
+ * "Lazy" tensors: between two convolutions the reference materialises norm(y) and relu_(norm(y)) (parts.py:19-31,
+ * 49-50).  Here a conv writes its RAW output y once, its epilogue leaves the BatchNorm / GroupNorm moments of y
+ * as partials, dram_norm_finalize_parts turns them into the per-row coefficients {a, b} (y_norm = a*y + b), and
+ * every consumer of the activated tensor -- the next conv (forward and backward-weights), the 2x2x2 max-pool,
+ * the trilinear upsample, the 1x1x1 head -- takes (y, coef, relu) and applies max(a*y + b, relu ? 0 : -inf)
+ * while loading.  The activated tensor never exists in HBM; values are bit-identical to dram_row_affine_act's.
+ *   coefK: [N*CK][2] floats, NULL = that source is an ordinary tensor;  reluK: apply ReLU after the affine map.
+ */
+
+/* number of statistics partials per (n, c) row that dram_conv3d_k3_fwd_fused writes for this shape (0: bad shape) */
+int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W);
+
+/* y = conv3d(act1(x1) ++ crop(act2(x2)), w) as dram_conv3d_k3_fwd_cat, each source lazily normalised (above), and --
+ * when stats != NULL -- per (row of y, part) {mean, M2, count} of the outputs into stats[N*Cout][nparts][3]
+ * (nparts = dram_conv3d_k3_stats_parts; two-pass moments per 64 outputs, no E[x^2]-E[x]^2).  stats and bias
+ * exclude each other (a conv followed by a norm has no bias, models.py:78). */
+int dram_conv3d_k3_fwd_fused(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2,
+                             const float* coef2, int relu2, int D2, int H2, int W2, int oz, int oy, int ox,
+                             const float* wt, const float* bias, float* y, float* stats, int nparts, int N,
+                             int Cout, int D, int H, int W, void* stream);
+
+/* 1 if backward-weights of this shape has the lazy-operand path (the Winograd kernel runs), else materialise x */
+int dram_conv3d_k3_wgrad_lazy_ok(int N, int C1, int C2, int Cout, int D, int H, int W);
+
+/* dram_conv3d_k3_wgrad_ex with lazily normalised x sources */
+int dram_conv3d_k3_wgrad_fused(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2,
+                               const float* coef2, int relu2, int D2, int H2, int W2, int oz, int oy, int ox,
+                               const float* dy, float* dw, void* ws, size_t ws_bytes, int N, int Cout, int D,
+                               int H, int W, void* stream);
+
+/* Training-mode BatchNorm / GroupNorm statistics (parts.py:19-31) from the conv epilogue's partials: save_mean,
+ * save_rstd per statistic, rowcoef[N*C][2], running statistics updated as dram_norm_fwd_train does.  Chan's
+ * combine in fp64; a total count that differs from the statistic's population poisons it with NaN. */
+size_t dram_norm_parts_ws_bytes(int N, int C, int nparts);
+int dram_norm_finalize_parts(const float* parts, int nparts, const float* gamma, const float* beta,
+                             float* save_mean, float* save_rstd, float* rowcoef, float* running_mean,
+                             float* running_var, float momentum, float eps, int kind, int G, int N, int C,
+                             int64_t S, void* ws, size_t ws_bytes, void* stream);
+
+/* eval-mode BatchNorm: rowcoef (and save_mean / save_rstd) from the running statistics, no pass over a tensor */
+int dram_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float* save_mean, float* save_rstd, float* rowcoef, float eps, int N, int C, void* stream);
+
+/* y = act(rowcoef[row][0] * x + rowcoef[row][1]): materialise a lazy tensor (rows = N*C) */
+int dram_row_affine_act(const float* x, const float* rowcoef, float* y, int relu, int64_t rows, int64_t S,
+                        void* stream);
+
+/* nn.MaxPool3d(2,2,0) (parts.py:191) of a lazy tensor; and its backward ADDED onto dx (the skip branch's gradient) */
+int dram_maxpool3d_2_fwd_lazy(const float* x, const float* coef, int relu, float* out, uint8_t* idx, int N, int C,
+                              int D, int H, int W, void* stream);
+int dram_maxpool3d_2_bwd_acc(const float* dout, const uint8_t* idx, float* dx, int N, int C, int D, int H,
+                             int W, void* stream);
+
+/* nn.Upsample(trilinear, align_corners=True) (parts.py:149) of a lazy tensor */
+int dram_upsample_trilinear_ac_fwd_lazy(const float* x, const float* coef, int relu, float* y, int N, int C, int D,
+                                        int H, int W, int Do, int Ho, int Wo, void* stream);
+
+/* top_layer 1x1x1 conv (models.py:109,145) of a lazy tensor, and its backward (dx = gradient w.r.t. act(x)) */
+int dram_conv3d_k1_fwd_lazy(const float* x, const float* coef, int relu, const float* w, const float* bias, float* y,
+                            int N, int Cin, int Cout, int64_t S, void* stream);
+int dram_conv3d_k1_bwd_lazy(const float* dy, const float* x, const float* coef, int relu, const float* w, float* dx,
+                            float* dw, float* dbias, void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif
