@@ -279,6 +279,7 @@ def main():
                        "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,
                        "parallelism": f"dp{world}"},
             "per_gpu_voxels_per_s": value / world,
+            "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
             # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 where the
             # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
             "network_executed_frac_of_fp32_peak": value / world * flops_per_voxel * exec_ratio / (PEAK_FP32_MFMA_TFLOPS * 1e12),

@@ -21,6 +21,8 @@ Not an oracle and not a fallback: every step is a kernel of libdram_hip.so.  Net
 (SyncBatchNorm, PReLU, dropout, `lite` blocks, conv kernels other than 3x3x3, checkpoint_mode="recompute") run the
 per-op path.
 """
+import os as _os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -54,18 +56,29 @@ class Lazy:
         return y
 
 
+# An UpsampleConvBlock5d's upsampled tensor is the largest activation of the network (128 channels at full
+# resolution in us_modules.2: 22 % of everything the per-op path saves).  Backward needs it once, as the x operand
+# of the first conv's backward-weights.  It is kept when small, and produced again from the low-resolution lazy
+# tensor (one bandwidth pass, ~0.3 % of a step) when it is larger than this fraction of the device memory.
+KEEP_UPSAMPLED_BELOW = float(_os.environ.get("DRAM_KEEP_UPSAMPLED_FRAC", "0.08"))
+
+
 class Upsampled:
-    """The x`scale` trilinear (align_corners=True) upsampling of a Lazy, as a recipe: produced when needed, not kept."""
-    __slots__ = ("src", "size")
+    """The x`scale` trilinear (align_corners=True) upsampling of a Lazy, as a recipe (see KEEP_UPSAMPLED_BELOW)."""
+    __slots__ = ("src", "size", "kept")
 
     def __init__(self, src, size):
-        self.src, self.size = src, tuple(int(v) for v in size)
+        self.src, self.size, self.kept = src, tuple(int(v) for v in size), None
 
-    def produce(self):
+    def produce(self, may_keep=False):
+        if self.kept is not None:
+            return self.kept
         N, C, D, H, W = self.src.raw.shape
         y = torch.empty((N, C) + self.size, dtype=torch.float32, device=self.src.raw.device)
         call("dram_upsample_trilinear_ac_fwd_lazy", _p(self.src.raw), _p(self.src.coef), int(self.src.relu), _p(y), N, C,
              D, H, W, *self.size, _stream())
+        if may_keep and y.numel() * 4 < KEEP_UPSAMPLED_BELOW * torch.cuda.get_device_properties(y.device).total_memory:
+            self.kept = y
         return y
 
 
@@ -129,7 +142,7 @@ def _norm_plan(norm, training):
 def _conv_stage(conv, norm, inp, skip, training, record):
     """y = conv(inp ++ crop(skip)) with the moments of y from the epilogue -> Lazy(y, coef, relu).  `inp` is a Lazy or
     an Upsampled recipe (then produced here, used, and dropped)."""
-    src = inp.produce() if isinstance(inp, Upsampled) else None
+    src = inp.produce(may_keep=record is not None) if isinstance(inp, Upsampled) else None
     x1 = Lazy(src) if src is not None else inp
     N, C1, D, H, W = x1.raw.shape
     w = conv.weight
@@ -323,8 +336,12 @@ def backward(model, record, gout, need_dx):
             dgamma = torch.empty(Co, dtype=torch.float32, device=g.device) if gamma is not None else None
             dbeta = torch.empty(Co, dtype=torch.float32, device=g.device) if s.norm.bias is not None else None
             ws = _ws(_lib.lib.dram_norm_ws_bytes(N, Co, S), g.device)
-            call("dram_norm_bwd", _p(g), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(g), _p(dgamma), _p(dbeta),
+            g_in = g
+            if _os.environ.get("DRAM_ENGINE_NO_INPLACE"):
+                g = torch.empty_like(g_in)
+            call("dram_norm_bwd", _p(g_in), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(g), _p(dgamma), _p(dbeta),
                  s.kind, s.groups, 1, int(s.batch_stats), N, Co, S, _p(ws), ws.numel(), st)
+            del g_in
             if dgamma is not None:
                 grads[gamma] = dgamma
             if dbeta is not None:
@@ -333,13 +350,15 @@ def backward(model, record, gout, need_dx):
             # backward-weights: the x operand is the stage's lazy input(s); an upsampled input is produced again
             inp = s.inp
             up_tmp = inp.produce() if isinstance(inp, Upsampled) else None
+            if up_tmp is not None:
+                inp.kept = None                      # last use: released after this stage
             x1 = Lazy(up_tmp) if up_tmp is not None else inp
             skip = s.skip
             dw = torch.empty_like(w)
             wsb = _ws(_lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W), g.device)
             name = HF.conv_wgrad_kernel_name((D, H, W), Co, Ci if skip is None else None,
                                              lazy=(x1.coef is not None or (skip is not None and skip.coef is not None)))
-            lazy_ok = bool(_lib.lib.dram_conv3d_k3_wgrad_lazy_ok(N, C1, C2, Co, D, H, W))
+            lazy_ok = bool(_lib.lib.dram_conv3d_k3_wgrad_lazy_ok(N, C1, C2, Co, D, H, W)) and not _os.environ.get("DRAM_ENGINE_NO_LAZY_WGRAD")
             if not lazy_ok:     # kernels without the on-load path (odd widths, first layer): plain operands
                 x1 = Lazy(x1.materialise())
                 skip_w = Lazy(skip.materialise()) if skip is not None else None
