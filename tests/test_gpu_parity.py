@@ -541,22 +541,29 @@ def test_dc3d_full_golden(golden_dir):
 
 
 def test_checkpoint_modes_agree(golden_dir):
-    """DC3D.checkpoint_mode 'stats' (no recomputation, BatchNorm buffers updated twice) and
-    'recompute' (torch.utils.checkpoint like the reference) give the same step."""
+    """DC3D.checkpoint_mode 'stats' (no recomputation, BatchNorm buffers updated twice) and 'recompute'
+    (torch.utils.checkpoint like the reference) give the same step: bit for bit on the per-op path (same kernels, same
+    inputs), and to rounding when 'stats' runs through the fused engine (its norm statistics are summed in a
+    different order)."""
     import models
     z = np.load(os.path.join(golden_dir, "dc3d_slim.npz"))
     res = {}
-    for mode in ("stats", "recompute"):
+    for mode, fused in (("stats", False), ("recompute", False), ("stats", True)):
         model = models.DC3D(**SLIM)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in _sub(z, "slim_bn/sd/").items()})
         model.checkpoint_mode = mode
+        model.fused = fused
         model = model.to(DEV).train()
         d0, _ = model(dev(torch.from_numpy(z["slim_bn/x"])))
         (d0 * dev(torch.from_numpy(z["slim_bn/gout"]))).sum().backward()
-        res[mode] = (d0.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters()},
-                     {k: v.cpu().double() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
-    assert torch.equal(res["stats"][0], res["recompute"][0])
-    for k in res["stats"][1]:
-        assert torch.equal(res["stats"][1][k], res["recompute"][1][k]), k     # same kernels, same inputs: bit-exact
-    for k in res["stats"][2]:
-        check(res["stats"][2][k], res["recompute"][2][k], f"buffer {k}", tol=1e-6)
+        res[(mode, fused)] = (d0.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters()},
+                              {k: v.cpu().double() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b, c = res[("stats", False)], res[("recompute", False)], res[("stats", True)]
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k     # same kernels, same inputs: bit-exact
+    for k in a[2]:
+        check(a[2][k], b[2][k], f"buffer {k}", tol=1e-6)
+    check(c[0], b[0], "fused engine output", tol=1e-5)
+    for k in c[2]:
+        check(c[2][k], b[2][k], f"fused engine buffer {k}", tol=1e-5)
