@@ -153,6 +153,73 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
     }
 }
 
+// Four consecutive x outputs per thread, for magnifications of 1.5x and more along x (scale <= 0.6: the four outputs
+// read at most four consecutive source columns): per (z,y) tap row ONE 16-byte load of the source columns
+// [xs, xs+3] instead of eight 4-byte loads, one 16-byte store instead of four 4-byte ones.  The z and y blends are
+// applied to the four source columns first and the x blend last (ATen blends x first: same terms, different rounding
+// order -- both are fp32 evaluations of the same trilinear form).
+__device__ __forceinline__ float sel4(const float (&t)[4], int i) {
+    return i == 0 ? t[0] : (i == 1 ? t[1] : (i == 2 ? t[2] : t[3]));
+}
+__global__ __launch_bounds__(256) void trilinear_fwd_x4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               Axis az, Axis ay, Axis ax, int planes,
+                                                               const float* __restrict__ coef, int relu) {
+    const int Wo4 = ax.out >> 2;
+    const int So4 = az.out * ay.out * Wo4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= So4) return;
+    const int xq = e % Wo4, yo = (e / Wo4) % ay.out, zo = e / (Wo4 * ay.out);
+    int z0, z1, y0, y1;
+    float a0, a1, b0, b1;
+    src_index(az, zo, z0, z1, a0, a1);
+    src_index(ay, yo, y0, y1, b0, b1);
+    int r0[4], r1[4];
+    float c0[4], c1[4];
+    int xs = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int i0, i1;
+        src_index(ax, 4 * xq + k, i0, i1, c0[k], c1[k]);
+        if (k == 0) xs = i0 < ax.in - 4 ? i0 : ax.in - 4;     // keep the 16-byte load inside the row
+        r0[k] = i0 - xs;
+        r1[k] = i1 - xs;
+    }
+    const int H = ay.in, W = ax.in;
+    const int64_t Si = (int64_t)az.in * H * W, So = (int64_t)az.out * ay.out * ax.out;
+    const int o00 = (z0 * H + y0) * W + xs, o01 = (z0 * H + y1) * W + xs;
+    const int o10 = (z1 * H + y0) * W + xs, o11 = (z1 * H + y1) * W + xs;
+    const int p0 = blockIdx.y * TRI_CPT;
+    const float lo = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        const float* p = x + (int64_t)plane * Si;
+        float v00[4], v01[4], v10[4], v11[4];
+        __builtin_memcpy(v00, p + o00, 16);     // 4-byte aligned 16-byte loads (global_load_dwordx4)
+        __builtin_memcpy(v01, p + o01, 16);
+        __builtin_memcpy(v10, p + o10, 16);
+        __builtin_memcpy(v11, p + o11, 16);
+        if (coef) {   // the source is a RAW conv output: interpolate act(a*x + b) (normalise + ReLU on load)
+            const float ca = coef[2 * plane], cb = coef[2 * plane + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v00[j] = fmaxf(fmaf(ca, v00[j], cb), lo); v01[j] = fmaxf(fmaf(ca, v01[j], cb), lo);
+                v10[j] = fmaxf(fmaf(ca, v10[j], cb), lo); v11[j] = fmaxf(fmaf(ca, v11[j], cb), lo);
+            }
+        }
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = a0 * (b0 * v00[j] + b1 * v01[j]) + a1 * (b0 * v10[j] + b1 * v11[j]);
+        float4 o;
+        o.x = c0[0] * sel4(t, r0[0]) + c1[0] * sel4(t, r1[0]);
+        o.y = c0[1] * sel4(t, r0[1]) + c1[1] * sel4(t, r1[1]);
+        o.z = c0[2] * sel4(t, r0[2]) + c1[2] * sel4(t, r1[2]);
+        o.w = c0[3] * sel4(t, r0[3]) + c1[3] * sel4(t, r1[3]);
+        *reinterpret_cast<float4*>(y + (int64_t)plane * So + 4 * (int64_t)e) = o;
+    }
+}
+
 // Adjoint in gather form.  For input index i the outputs that touch it form the contiguous range
 // [lo, hi] = {o : i0(o) in {i-1, i}}; each contributes l0(o) if i0(o)==i plus l1(o) if i1(o)==i.
 __device__ __forceinline__ void touch_range(const Axis& a, int i, int& lo, int& hi) {
@@ -459,15 +526,29 @@ extern "C" int dram_maxpool3d_2_bwd_acc(const float* dout, const uint8_t* idx, f
     return maxpool_bwd_run("maxpool3d_2_bwd_acc", dout, idx, dx, N, C, D, H, W, 1, stream);
 }
 
+// 16-byte path of the forward resize: x magnification >= 1.67, rows of >= 4 source columns, 16-byte aligned output rows
+static bool tri_fwd_x4_ok(const float* y, const Axis& ax) {
+    return ax.half == 0 && ax.in >= 4 && (ax.out % 4) == 0 && ax.scale <= 0.6f && (((uintptr_t)y) & 15) == 0;
+}
+static int tri_fwd_launch(const float* x, float* y, const Axis& az, const Axis& ay, const Axis& ax, int planes, const float* coef,
+                          int relu, hipStream_t st) {
+    if (tri_fwd_x4_ok(y, ax)) {
+        dim3 grid(cdiv(az.out * ay.out * (ax.out / 4), 256), cdiv(planes, TRI_CPT));
+        hipLaunchKernelGGL(trilinear_fwd_x4_kernel, grid, dim3(256), 0, st, x, y, az, ay, ax, planes, coef, relu);
+    } else {
+        dim3 grid(cdiv(az.out * ay.out * ax.out, 256), cdiv(planes, TRI_CPT));
+        hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, st, x, y, az, ay, ax, planes, coef, relu);
+    }
+    return DRAM_OK;
+}
+
 extern "C" int dram_upsample_trilinear_ac_fwd(const float* x, float* y, int N, int C, int D, int H, int W, int Do,
                                               int Ho, int Wo, void* stream) {
     DRAM_REQUIRE(x && y, "upsample_trilinear_ac_fwd: null pointer");
     DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_fwd: bad sizes");
     int rc = check_planes("upsample_trilinear_ac_fwd", (int64_t)N * C, (int64_t)Do * Ho * Wo);
     if (rc) return rc;
-    dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
-    hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
-                       make_axis(H, Ho), make_axis(W, Wo), N * C, (const float*)nullptr, 0);
+    tri_fwd_launch(x, y, make_axis(D, Do), make_axis(H, Ho), make_axis(W, Wo), N * C, nullptr, 0, (hipStream_t)stream);
     return check_launch("upsample_trilinear_ac_fwd");
 }
 
@@ -478,9 +559,7 @@ extern "C" int dram_upsample_trilinear_ac_fwd_lazy(const float* x, const float* 
     DRAM_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "upsample_trilinear_ac_fwd_lazy: bad sizes");
     int rc = check_planes("upsample_trilinear_ac_fwd_lazy", (int64_t)N * C, (int64_t)Do * Ho * Wo);
     if (rc) return rc;
-    dim3 grid(cdiv(Do * Ho * Wo, 256), cdiv(N * C, TRI_CPT));
-    hipLaunchKernelGGL(trilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, make_axis(D, Do),
-                       make_axis(H, Ho), make_axis(W, Wo), N * C, coef, relu);
+    tri_fwd_launch(x, y, make_axis(D, Do), make_axis(H, Ho), make_axis(W, Wo), N * C, coef, relu, (hipStream_t)stream);
     return check_launch("upsample_trilinear_ac_fwd_lazy");
 }
 

@@ -51,11 +51,16 @@ def test_fused_engine_equals_per_op_path(norm, N, shape, need_dx):
     model = models.DC3D(**SLIM, norm_method=norm)
     model.init(models.HeNorm(mode="fan_in"))
     g = torch.Generator().manual_seed(8)
-    with torch.no_grad():       # non-trivial affine parameters
+    # Non-trivial affine parameters, with biases of +-3 sigma: pre-activations then stay away from zero (density
+    # 4e-3 there instead of 0.4), so that no ReLU mask bit can flip between the two paths because their statistics
+    # differ in the last bit -- at the 2x2x2 bottleneck of these small volumes ONE flip moves a gradient by percents
+    # (measured).  Spatially mixed masks are pinned by the reference goldens, which run through the engine too.
+    with torch.no_grad():
         for m in model.modules():
             if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.GroupNorm)) and m.weight is not None:
                 m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
-                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                sign = torch.where(torch.arange(m.bias.numel()) % 3 == 2, -1.0, 1.0)
+                m.bias.copy_(3.0 * sign * m.weight.abs())
     model = model.to(DEV).train()
     assert engine.supports(model)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
@@ -71,8 +76,7 @@ def test_fused_engine_equals_per_op_path(norm, N, shape, need_dx):
     got = _run(model, x, gout, True, need_dx)
     assert _rel(got[0], ref[0]) <= 2e-5, ("out", _rel(got[0], ref[0]))
     worst = {k: _rel(got[1][k], ref[1][k]) for k in ref[1]}
-    # typical agreement 1e-6; the bound leaves room for a mask flip or two (each ~1/n of a sum without cancellation)
-    tol = 2e-3
+    tol = 1e-4           # typical agreement 1e-6
     print(f"\n{norm} {N}x{shape}: worst gradient difference {max(worst.values()):.2e}")
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
