@@ -63,6 +63,15 @@ class Lazy:
 KEEP_UPSAMPLED_BELOW = float(_os.environ.get("DRAM_KEEP_UPSAMPLED_FRAC", "0.08"))
 
 
+# Lazy tensors trade time for memory: applying the norm on load costs the consumer kernels 3-6 % (forward conv) and
+# 4-5 % (backward-weights) of their time (scripts/bench_fused.py), a materialising pass costs one read + one write of
+# the tensor and 4 bytes per element of HBM until backward.  So a stage's activated output is written when it is
+# small (below this fraction of the device memory) and stays lazy when it is large: with the 64 x 128^3 benchmark at
+# micro-batch 16 everything is written (8.6 GB per full-resolution tensor = 3 %), at micro-batch 32 the
+# full-resolution stages stay lazy and the step fits 288 GB.
+MATERIALISE_BELOW = float(_os.environ.get("DRAM_MATERIALISE_FRAC", "0.04"))
+
+
 class Upsampled:
     """The x`scale` trilinear (align_corners=True) upsampling of a Lazy, as a recipe (see KEEP_UPSAMPLED_BELOW)."""
     __slots__ = ("src", "size", "kept")
@@ -188,6 +197,8 @@ def _conv_stage(conv, norm, inp, skip, training, record):
                        0, N, Co, D, H, W, st)
         call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
     out = Lazy(y, coef, relu=True)
+    if record is not None and y.numel() * 4 < MATERIALISE_BELOW * torch.cuda.get_device_properties(dev).total_memory:
+        out = Lazy(out.materialise())        # (inference keeps everything lazy: nothing is kept there anyway)
     if record is not None:
         s = _Stage()
         s.conv, s.norm, s.inp, s.skip = conv, norm, inp, skip
