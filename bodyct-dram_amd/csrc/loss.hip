@@ -165,6 +165,88 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
 }
 
+
+// ---- pieces of the affine-consistency losses (IntRegAffRefineLoss, dram/metrics.py:376-462) -----------------------
+// F.sigmoid as its own differentiable op (the consistency term compares probabilities), and
+// F.smooth_l1_loss(a[m > 0], b[m > 0]) (beta = 1, mean) with the mask m[N,1,S] expanded over the C channels of a, b.
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        float p, q;
+        sigmoid_pq(x[e], p, q);
+        y[e] = p;
+    }
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        float p, q;
+        sigmoid_pq(x[e], p, q);          // p * (1 - p) with 1 - p at full relative accuracy
+        dx[e] = dy[e] * p * q;
+    }
+}
+
+// part[(row*nchunks + chunk)*2] = {sum of the smooth-L1 terms over masked elements, number of masked elements}
+__global__ __launch_bounds__(256) void masked_smooth_l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                       const float* __restrict__ mask, float* __restrict__ part,
+                                                                       int C, int64_t S, int nchunks) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.y;            // n*C + c
+    const int n = (int)(row / C);
+    const int64_t beg = (int64_t)blockIdx.x * LCHUNK;
+    const int len = (int)((S - beg) < LCHUNK ? (S - beg) : LCHUNK);
+    const float* pa = a + row * S + beg;
+    const float* pb = b + row * S + beg;
+    const float* pm = mask + (int64_t)n * S + beg;
+    float s = 0.f, cnt = 0.f;
+    for (int e = threadIdx.x; e < len; e += 256) {
+        if (pm[e] > 0.f) {
+            const float d = fabsf(pa[e] - pb[e]);
+            s += d < 1.f ? 0.5f * d * d : d - 0.5f;
+            cnt += 1.f;
+        }
+    }
+    s = block_sum_256(s, red);
+    cnt = block_sum_256(cnt, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)row * nchunks + blockIdx.x) * 2] = s;
+        part[((size_t)row * nchunks + blockIdx.x) * 2 + 1] = cnt;
+    }
+}
+// out[0] = mean, out[1] = count; fixed-order fp64 sum by one block
+__global__ __launch_bounds__(256) void masked_smooth_l1_finalize_kernel(const float* __restrict__ part, int64_t items,
+                                                                        float* __restrict__ out) {
+    __shared__ double rs[4], rc[4];
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < items; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
+    s = wave_sum_d(s); c = wave_sum_d(c);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = rs[0] + rs[1] + rs[2] + rs[3], Cn = rc[0] + rc[1] + rc[2] + rc[3];
+        out[0] = (float)(S / Cn);          // an empty selection gives nan, like torch's mean of an empty tensor
+        out[1] = (float)Cn;
+    }
+}
+__global__ void masked_smooth_l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                            const float* __restrict__ mask, const float* __restrict__ out,
+                                            const float* __restrict__ gout, float* __restrict__ da, float* __restrict__ db,
+                                            int C, int64_t S) {
+    const int64_t row = blockIdx.y;
+    const int n = (int)(row / C);
+    const float g = gout[0] / out[1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < S; e += stride) {
+        float v = 0.f;
+        if (mask[(int64_t)n * S + e] > 0.f) {
+            const float d = a[row * S + e] - b[row * S + e];
+            v = g * fminf(fmaxf(d, -1.f), 1.f);      // d/dd of the smooth-L1 term: d inside (-1,1), sign(d) outside
+        }
+        if (da) da[row * S + e] = v;
+        if (db) db[row * S + e] = -v;
+    }
+}
+
 static inline int loss_chunks(int64_t S) { return (int)cdiv64(S, LCHUNK); }
 
 }  // namespace dram
@@ -208,4 +290,48 @@ extern "C" int dram_intreg_loss_bwd(const float* dense, const float* refined, co
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx ? gx : 1, N), dim3(256), 0, (hipStream_t)stream, dense, refined, lobes, lesions,
                        keep, targets, weight, state, gout, smoothing, ddense, drefined, S);
     return check_launch("intreg_loss_bwd");
+}
+
+extern "C" int dram_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
+    DRAM_REQUIRE(x && y && n > 0, "sigmoid_fwd: bad arguments");
+    const unsigned grid = (unsigned)(cdiv64(n, 256) < 8192 ? cdiv64(n, 256) : 8192);
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("sigmoid_fwd");
+}
+
+extern "C" int dram_sigmoid_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+    DRAM_REQUIRE(dy && x && dx && n > 0, "sigmoid_bwd: bad arguments");
+    const unsigned grid = (unsigned)(cdiv64(n, 256) < 8192 ? cdiv64(n, 256) : 8192);
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+    return check_launch("sigmoid_bwd");
+}
+
+extern "C" size_t dram_masked_smooth_l1_ws_bytes(int N, int C, int64_t S) {
+    if (N <= 0 || C <= 0 || S <= 0) return 0;
+    return (size_t)N * C * loss_chunks(S) * 2 * sizeof(float);
+}
+
+extern "C" int dram_masked_smooth_l1_fwd(const float* a, const float* b, const float* mask, float* out, void* ws,
+                                         size_t ws_bytes, int N, int C, int64_t S, void* stream) {
+    DRAM_REQUIRE(a && b && mask && out && ws, "masked_smooth_l1_fwd: null pointer");
+    DRAM_REQUIRE(N > 0 && C > 0 && S > 0 && (int64_t)N * C <= 65535, "masked_smooth_l1_fwd: bad dimensions");
+    if (ws_bytes < dram_masked_smooth_l1_ws_bytes(N, C, S)) {
+        set_error("masked_smooth_l1_fwd: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = loss_chunks(S);
+    hipLaunchKernelGGL(masked_smooth_l1_partial_kernel, dim3(nch, N * C), dim3(256), 0, st, a, b, mask, (float*)ws, C, S, nch);
+    hipLaunchKernelGGL(masked_smooth_l1_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int64_t)N * C * nch, out);
+    return check_launch("masked_smooth_l1_fwd");
+}
+
+extern "C" int dram_masked_smooth_l1_bwd(const float* a, const float* b, const float* mask, const float* out,
+                                         const float* gout, float* da, float* db, int N, int C, int64_t S, void* stream) {
+    DRAM_REQUIRE(a && b && mask && out && gout && (da || db), "masked_smooth_l1_bwd: null pointer");
+    DRAM_REQUIRE(N > 0 && C > 0 && S > 0 && (int64_t)N * C <= 65535, "masked_smooth_l1_bwd: bad dimensions");
+    const unsigned gx = (unsigned)(cdiv64(S, 256) < 2048 ? cdiv64(S, 256) : 2048);
+    hipLaunchKernelGGL(masked_smooth_l1_bwd_kernel, dim3(gx, N * C), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, gout,
+                       da, db, C, S);
+    return check_launch("masked_smooth_l1_bwd");
 }

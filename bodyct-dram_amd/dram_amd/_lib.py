@@ -91,6 +91,12 @@ SIGNATURES = {
     "dram_upsample_trilinear_ac_fwd_lazy": (I, [P, P, I, P, I, I, I, I, I, I, I, I, P]),
     "dram_conv3d_k1_fwd_lazy": (I, [P, P, I, P, P, P, I, I, I, L, P]),
     "dram_conv3d_k1_bwd_lazy": (I, [P, P, P, I, P, P, P, P, P, Z, I, I, I, L, P]),
+    # affine-consistency losses
+    "dram_sigmoid_fwd": (I, [P, P, L, P]),
+    "dram_sigmoid_bwd": (I, [P, P, P, L, P]),
+    "dram_masked_smooth_l1_ws_bytes": (Z, [I, I, L]),
+    "dram_masked_smooth_l1_fwd": (I, [P, P, P, P, P, Z, I, I, L, P]),
+    "dram_masked_smooth_l1_bwd": (I, [P, P, P, P, P, P, P, I, I, L, P]),
 }
 
 

@@ -660,6 +660,67 @@ def intreg_refine_loss(dense, lobes, lesions, keep, targets, weight, smoothing=0
     return IntRegRefineLossFn.apply(dense, refined, lobes, lesions, keep, targets, weight, smoothing)
 
 
+class SigmoidFn(Function):
+    """F.sigmoid as a differentiable device op (the affine-consistency term compares probabilities,
+    reference dram/metrics.py:434,445)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "sigmoid input")
+        y = torch.empty_like(x)
+        call("dram_sigmoid_fwd", _p(x), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "sigmoid grad_output")
+        dx = torch.empty_like(x)
+        call("dram_sigmoid_bwd", _p(dy), _p(x), _p(dx), x.numel(), _stream())
+        return dx
+
+
+def sigmoid(x):
+    return SigmoidFn.apply(x)
+
+
+class MaskedSmoothL1Fn(Function):
+    """F.smooth_l1_loss(a[m > 0], b[m > 0]) with m [N,1,D,H,W] expanded over the channels of a, b [N,C,D,H,W]
+    (reference dram/metrics.py:448-452)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        a, b, mask = _chk(a, "smooth_l1 input", 5), _chk(b, "smooth_l1 target", 5), _chk(mask, "smooth_l1 mask", 5)
+        N, C = a.shape[:2]
+        S = a.numel() // (N * C)
+        if b.shape != a.shape or mask.shape[0] != N or mask.shape[1] != 1 or mask.numel() != N * S:
+            raise ValueError(f"masked smooth-L1: shapes {tuple(a.shape)}, {tuple(b.shape)}, mask {tuple(mask.shape)}")
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        ws = _ws(_lib.lib.dram_masked_smooth_l1_ws_bytes(N, C, S), a.device)
+        call("dram_masked_smooth_l1_fwd", _p(a), _p(b), _p(mask), _p(out), _p(ws), ws.numel(), N, C, S, _stream())
+        ctx.save_for_backward(a, b, mask, out)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b, mask, out = ctx.saved_tensors
+        N, C = a.shape[:2]
+        S = a.numel() // (N * C)
+        g = g.reshape(1).contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            call("dram_masked_smooth_l1_bwd", _p(a), _p(b), _p(mask), _p(out), _p(g), _p(da), _p(db), N, C, S, _stream())
+        return da, db, None
+
+
+def masked_smooth_l1(a, b, mask):
+    return MaskedSmoothL1Fn.apply(a, b, mask)
+
+
 # --------------------------------------------------------------------------- PCM local attention
 PCM_RELU, PCM_L2NORM = 1, 2
 # merge_type -> (flags, scale_mode); reference models.py:259-331 (dot-product family)

@@ -177,3 +177,54 @@ class DataParallelTrainer:
         self.allreduce_gradients()
         self.opt.step()
         return tot_reg, tot_seg
+
+
+class DeviceIntRegAffRefineLoss:
+    """IntRegAffRefineLoss.__call__ (reference dram/metrics.py:376-462) on the device: the interval-regression and
+    pseudo-label losses of IntRegRefineLoss on a batch AND on an affinely transformed copy of it, plus the
+    consistency terms smooth_l1(T(sigmoid(dense)), sigmoid(dense_T)) and smooth_l1(T(cls), cls_T) inside the
+    transformed lobes.  The random transform T (rescale / flip / rot90 drawn as the reference draws them: same
+    `random` / `numpy.random` calls in the same order) runs on the OneShot kernels of dram_amd/transforms.py and
+    stays differentiable for the predictions.  The model returns (dense, refined, cls) like the 3-output
+    variants this loss was written for (metrics.py:432).  Returns (reg, aff, seg) as the reference does."""
+
+    def __init__(self, rescale_jitter, band_width=5e-2, smoothing=0.05, freq_map=None):
+        self.rescale_jitter, self.band_width, self.smoothing = rescale_jitter, band_width, smoothing
+        self.freq_map = freq_map or {k: 1.0 / 6 for k in range(6)}
+        self.loss = DeviceIntRegRefineLoss(band_width, smoothing)
+
+    def get_affine_transform(self):
+        """metrics.py:391-416: the three OneShot transforms in a random order, each kept with probability 1/2."""
+        import itertools
+        import random
+
+        import numpy as np
+
+        from .transforms import Flip3DOneShot, Rescale3DOneShot, Rotate903DOneShot
+        pool = [Rescale3DOneShot(self.rescale_jitter, None, mode='size'), Flip3DOneShot(), Rotate903DOneShot()]
+        order = list(random.sample(list(itertools.permutations(pool, 3)), 1)[0])
+        chosen = [t for t in order if np.random.randint(0, 10) < (10 * 0.5)]
+
+        def apply(sample):
+            for t in chosen:
+                sample = t(sample)
+            return sample
+        apply.p = chosen
+        return apply
+
+    def __call__(self, model, batch):
+        from . import functional as HF
+        T = self.get_affine_transform()
+        aff_images = T({"#image": batch.images})["#image"]
+        aff_lobes = T({"#reference": batch.lobes})["#reference"].contiguous()
+        aff_lesions = T({"#reference": batch.lesions})["#reference"].contiguous()
+        dense, refined, cls = model(batch.images, batch.lobes)
+        reg, seg = self.loss(dense, batch, refined=refined)
+        probs_T = T({"#image": HF.sigmoid(dense)})["#image"]
+        cls_T = T({"#image": cls})["#image"]
+        aff = Batch(aff_images.detach(), aff_lobes, aff_lesions, batch.ctss, self.freq_map, band_width=self.band_width)
+        a_dense, a_refined, a_cls = model(aff.images, aff.lobes)
+        a_reg, a_seg = self.loss(a_dense, aff, refined=a_refined)
+        aff_loss = HF.masked_smooth_l1(probs_T, HF.sigmoid(a_dense), aff.lobes)
+        aff_loss_cls = HF.masked_smooth_l1(cls_T, a_cls, aff.lobes)
+        return (reg + a_reg) / 2.0, (aff_loss + aff_loss_cls) / 2.0, (seg + a_seg) / 2.0

@@ -360,6 +360,19 @@ int dram_conv3d_k1_bwd_lazy(const float* dy, const float* x, const float* coef, 
                             float* dw, float* dbias, void* ws, size_t ws_bytes, int N, int Cin, int Cout, int64_t S,
                             void* stream);
 
+/* ---- affine-consistency losses (IntRegAffRefineLoss, dram/metrics.py:376-462): the two ops they add ----
+ * F.sigmoid (metrics.py:434,445) as a differentiable op: y = sigmoid(x); dx = dy * p * (1 - p) recomputed from x. */
+int dram_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int dram_sigmoid_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* F.smooth_l1_loss(a[m > 0], b[m > 0]) (metrics.py:449,451-452: beta 1, mean) for a, b [N,C,S] and the mask m[N,1,S]
+ * expanded over C.  out[0] = loss, out[1] = number of selected elements; deterministic (fp64, fixed order).
+ * Backward: da (and/or db = -da) for the upstream gradient gout[0]. */
+size_t dram_masked_smooth_l1_ws_bytes(int N, int C, int64_t S);
+int dram_masked_smooth_l1_fwd(const float* a, const float* b, const float* mask, float* out, void* ws,
+                              size_t ws_bytes, int N, int C, int64_t S, void* stream);
+int dram_masked_smooth_l1_bwd(const float* a, const float* b, const float* mask, const float* out,
+                              const float* gout, float* da, float* db, int N, int C, int64_t S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -493,6 +493,67 @@ def gen_clean(models):
     _save("dc3d_clean", **arrs)
 
 
+CASES_AFFLOSS = (("all3", 0), ("all3b", 12), ("fliprot", 7), ("rescale", 5), ("none", 1))
+
+
+def gen_affloss():
+    """IntRegAffRefineLoss (metrics.py:376-462) of the reference with a closed-form 3-output stand-in for the model
+    (dense / refined / 2-channel cls as smooth functions of the input and three scalar parameters), the random
+    affine transform drawn under fixed `random` / `numpy.random` seeds.  Stores inputs, the transform that was
+    drawn, the three loss values and the gradients of the parameters."""
+    import random
+    torch.Tensor.cuda = lambda self, *a, **k: self     # generator process only (metrics.py:136,173)
+    import metrics
+
+    class Obj:
+        ctss_frequency_map = {k: 1.0 / 6 for k in range(6)}
+        debug_path = "/tmp/_dram_golden_dbg"
+        epoch_n = 0
+    g = torch.Generator().manual_seed(91)
+    N, S = 4, 12
+    zz, yy, xx = np.meshgrid(*[np.arange(S)] * 3, indexing="ij")
+    lobe = (((zz - S / 2 + .5) ** 2 + (yy - S / 2 + .5) ** 2 + (xx - S / 2 + .5) ** 2) < (0.45 * S) ** 2)
+    lobes = torch.from_numpy(lobe.astype(np.float32))[None, None].repeat(N, 1, 1, 1, 1)
+    images = torch.rand(N, 1, S, S, S, generator=g) * lobes
+    lesions = ((images > 0.7) & (lobes > 0)).float()
+    ctss = [float(1 + n % 5) for n in range(N)]
+    theta = torch.tensor([1.5, -0.4, 0.8], requires_grad=True)
+
+    def fake_model(imgs, lbs):
+        a, b, c = theta[0], theta[1], theta[2]
+        D, H, W = imgs.shape[-3:]      # position-dependent terms: the stand-in must not commute with flips / rotations
+        rz = torch.linspace(0.0, 1.0, D).view(1, 1, D, 1, 1)
+        rx = torch.linspace(0.0, 1.0, W).view(1, 1, 1, 1, W)
+        dense = a * (imgs - 0.5) * 4.0 + b + 0.6 * c * rx - 0.4 * rz
+        refined = 0.7 * dense - c * imgs
+        cls = torch.cat([a * imgs + rz, imgs * imgs + b * c * rx], dim=1)
+        return dense, refined, cls
+    fake_model.trace_path = None
+    arrs = {}
+    for case, seed in CASES_AFFLOSS:
+        random.seed(seed)
+        np.random.seed(seed)
+        loss_fn = metrics.IntRegAffRefineLoss(rescale_jitter=[8, 10, 12, 14], band_width=5e-2, smoothing=0.05)
+        T_holder = {}
+        orig = loss_fn.get_affine_transform
+
+        def spy():
+            T_holder["T"] = orig()
+            return T_holder["T"]
+        loss_fn.get_affine_transform = spy
+        theta.grad = None
+        reg, aff, seg = loss_fn(fake_model, images, lobes, lesions, ctss, obj=Obj(), metas=None)
+        (2.0 * reg + 0.5 * aff + 1.0 * seg).backward()
+        desc = [f"{type(t).__name__}:" + ",".join(f"{k}={v}" for k, v in sorted(t.__dict__.items()) if k != "rescale_factor_pool")
+                for t in T_holder["T"].p]
+        print("affloss", case, seed, desc, reg.item(), aff.item(), seg.item(), theta.grad.tolist())
+        arrs[f"{case}/seed"] = np.array(seed)
+        arrs[f"{case}/T"] = np.array("|".join(desc))
+        arrs[f"{case}/out"] = np.array([reg.item(), aff.item(), seg.item()])
+        arrs[f"{case}/gtheta"] = _np(theta.grad)
+    _save("affloss", images=_np(images), lobes=_np(lobes), lesions=_np(lesions), ctss=np.array(ctss), theta=_np(theta), **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     parts, models = _import_reference()
@@ -515,3 +576,5 @@ if __name__ == "__main__":
         gen_loss()
     if not only or "loss2" in only:
         gen_loss2()
+    if not only or "affloss" in only:
+        gen_affloss()

@@ -107,3 +107,56 @@ def test_trainer_step_matches_oracle(golden_dir):
                 err = (got[k] - e).abs().max().item()
                 assert err <= 2e-2 * step_ref + 1e-9, (k, err, step_ref)
         m = m.cpu()
+
+
+AFF_CASES = ["all3", "all3b", "fliprot", "rescale", "none"]
+
+
+@pytest.mark.parametrize("case", AFF_CASES)
+def test_affine_consistency_loss_matches_reference_golden(golden_dir, case):
+    """DeviceIntRegAffRefineLoss against the reference's IntRegAffRefineLoss (dram/metrics.py:376-462) run in the build
+    container (tests/golden/affloss.npz, oracle/make_golden.py:gen_affloss): same `random` / `numpy.random` seeds ->
+    the same affine transform is drawn (checked), then the three loss values and the gradients of the stand-in
+    model's parameters.  The stand-in (closed-form dense / refined / 2-channel cls outputs with position-dependent
+    terms) is test scaffolding written with torch ops; everything of the loss itself -- OneShot transforms, sigmoid,
+    the fused interval-regression / pseudo-label loss, masked smooth-L1 -- runs on the kernels."""
+    import random
+    from dram_amd.train_step import Batch, DeviceIntRegAffRefineLoss
+    z = np.load(os.path.join(golden_dir, "affloss.npz"))
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    ctss = list(z["ctss"])
+    batch = Batch(t("images"), t("lobes"), t("lesions"), ctss, FREQ, band_width=5e-2)
+    theta = torch.from_numpy(z["theta"]).cuda().requires_grad_(True)
+
+    def standin(imgs, lbs):
+        a, b, c = theta[0], theta[1], theta[2]
+        D, H, W = imgs.shape[-3:]
+        rz = torch.linspace(0.0, 1.0, D, device=imgs.device).view(1, 1, D, 1, 1)
+        rx = torch.linspace(0.0, 1.0, W, device=imgs.device).view(1, 1, 1, 1, W)
+        dense = a * (imgs - 0.5) * 4.0 + b + 0.6 * c * rx - 0.4 * rz
+        refined = 0.7 * dense - c * imgs
+        cls = torch.cat([a * imgs + rz, imgs * imgs + b * c * rx], dim=1)
+        return dense, refined, cls
+
+    seed = int(z[f"{case}/seed"])
+    random.seed(seed)
+    np.random.seed(seed)
+    loss = DeviceIntRegAffRefineLoss(rescale_jitter=[8, 10, 12, 14], band_width=5e-2, smoothing=0.05, freq_map=FREQ)
+    drawn = {}
+    orig = loss.get_affine_transform
+
+    def spy():
+        drawn["T"] = orig()
+        return drawn["T"]
+    loss.get_affine_transform = spy
+    reg, aff, seg = loss(standin, batch)
+    got_T = [type(x).__name__ for x in drawn["T"].p]
+    want_T = [d.split(":")[0] for d in str(z[f"{case}/T"]).split("|") if d]
+    assert got_T == want_T, (got_T, want_T)
+    ref = z[f"{case}/out"]
+    for name, g_, r_ in zip(("reg", "aff", "seg"), (reg, aff, seg), ref):
+        assert abs(float(g_) - float(r_)) <= 2e-5 * max(1.0, abs(float(r_))), (case, name, float(g_), float(r_))
+    (2.0 * reg + 0.5 * aff + 1.0 * seg).backward()
+    gref = z[f"{case}/gtheta"]
+    err = np.abs(theta.grad.cpu().numpy() - gref).max() / np.abs(gref).max()
+    assert err <= 1e-4, (case, err, theta.grad.tolist(), gref.tolist())
