@@ -79,14 +79,18 @@ class Upsampled:
     def __init__(self, src, size):
         self.src, self.size, self.kept = src, tuple(int(v) for v in size), None
 
-    def produce(self, may_keep=False):
-        if self.kept is not None:
-            return self.kept
+    def produce(self, lo=0, hi=None, may_keep=False):
+        """The upsampled tensor of samples [lo, hi) (default: all)."""
         N, C, D, H, W = self.src.raw.shape
-        y = torch.empty((N, C) + self.size, dtype=torch.float32, device=self.src.raw.device)
-        call("dram_upsample_trilinear_ac_fwd_lazy", _p(self.src.raw), _p(self.src.coef), int(self.src.relu), _p(y), N, C,
-             D, H, W, *self.size, _stream())
-        if may_keep and y.numel() * 4 < KEEP_UPSAMPLED_BELOW * torch.cuda.get_device_properties(y.device).total_memory:
+        hi = N if hi is None else hi
+        if self.kept is not None:
+            return self.kept[lo:hi]
+        n = hi - lo
+        y = torch.empty((n, C) + self.size, dtype=torch.float32, device=self.src.raw.device)
+        call("dram_upsample_trilinear_ac_fwd_lazy", _p(self.src.raw[lo:hi]), _p(_rows(self.src.coef, lo, hi, C)),
+             int(self.src.relu), _p(y), n, C, D, H, W, *self.size, _stream())
+        if may_keep and (lo, hi) == (0, N) and \
+                y.numel() * 4 < KEEP_UPSAMPLED_BELOW * torch.cuda.get_device_properties(y.device).total_memory:
             self.kept = y
         return y
 
@@ -148,12 +152,38 @@ def _norm_plan(norm, training):
     return NORM_BATCH, 1, use_batch, rm, rv, eaf
 
 
+# A stage whose first input is an Upsampled recipe runs in slices of samples when the upsampled tensor (and, in
+# backward, its gradient) would exceed this fraction of the device memory: every kernel of the stage is independent
+# per sample, only the norm statistics span the batch -- and they are finalised once, over all slices' partials.
+# That is what lets 64 x 128^3 chunks go through as ONE batch (whole-batch BatchNorm statistics, like the reference).
+SLICE_UPSAMPLED_ABOVE = float(_os.environ.get("DRAM_SLICE_UPSAMPLED_FRAC", "0.08"))
+
+
+def _rows(coef, lo, hi, C):
+    return None if coef is None else coef[2 * lo * C:2 * hi * C]
+
+
+def _lazy_slice(lz, lo, hi):
+    return Lazy(lz.raw[lo:hi], _rows(lz.coef, lo, hi, lz.raw.shape[1]), lz.relu)
+
+
+def _slices(inp, N):
+    """Sample ranges in which a stage with input `inp` is executed."""
+    if not isinstance(inp, Upsampled) or inp.kept is not None:
+        return [(0, N)]
+    C = inp.src.raw.shape[1]
+    per_sample = 4 * C * inp.size[0] * inp.size[1] * inp.size[2]
+    budget = SLICE_UPSAMPLED_ABOVE * torch.cuda.get_device_properties(inp.src.raw.device).total_memory
+    n = max(1, min(N, int(budget // per_sample)))
+    return [(lo, min(N, lo + n)) for lo in range(0, N, n)]
+
+
 def _conv_stage(conv, norm, inp, skip, training, record):
     """y = conv(inp ++ crop(skip)) with the moments of y from the epilogue -> Lazy(y, coef, relu).  `inp` is a Lazy or
-    an Upsampled recipe (then produced here, used, and dropped)."""
-    src = inp.produce(may_keep=record is not None) if isinstance(inp, Upsampled) else None
-    x1 = Lazy(src) if src is not None else inp
-    N, C1, D, H, W = x1.raw.shape
+    an Upsampled recipe (then produced here -- whole, or slice by slice -- used, and dropped unless it is small)."""
+    up = isinstance(inp, Upsampled)
+    N, C1 = inp.src.raw.shape[:2] if up else inp.raw.shape[:2]
+    D, H, W = inp.size if up else inp.raw.shape[2:]
     w = conv.weight
     Co, Ci = w.shape[0], w.shape[1]
     dev = w.device
@@ -176,25 +206,29 @@ def _conv_stage(conv, norm, inp, skip, training, record):
     rstd = torch.empty(nstat, dtype=torch.float32, device=dev)
     coef = torch.empty(2 * N * Co, dtype=torch.float32, device=dev)
     gamma, beta = norm.weight, norm.bias
-    vox = N * S
     name = HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True)
-    if use_batch:
-        nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W)
-        parts = torch.empty(N * Co * nparts * 3, dtype=torch.float32, device=dev)
+    nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W) if use_batch else 0
+    parts = torch.empty(N * Co * nparts * 3, dtype=torch.float32, device=dev) if use_batch else None
+    ranges = _slices(inp, N) if up else [(0, N)]
+    for lo, hi in ranges:
+        n = hi - lo
+        if up:
+            x1 = Lazy(inp.produce(lo, hi, may_keep=record is not None and len(ranges) == 1))
+        else:
+            x1 = inp if (lo, hi) == (0, N) else _lazy_slice(inp, lo, hi)
+        sk = None if skip is None else (skip if (lo, hi) == (0, N) else _lazy_slice(skip, lo, hi))
+        vox = n * S
         HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                        "dram_conv3d_k3_fwd_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
-                       _p(skip.raw) if skip is not None else None, C2, _p(skip.coef) if skip is not None else None,
-                       int(skip.relu) if skip is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y), _p(parts),
-                       nparts, N, Co, D, H, W, st)
+                       _p(sk.raw) if sk is not None else None, C2, _p(sk.coef) if sk is not None else None,
+                       int(sk.relu) if sk is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y[lo:hi]),
+                       _p(parts[lo * Co * nparts * 3:]) if use_batch else None, nparts, n, Co, D, H, W, st)
+        del x1
+    if use_batch:
         ws = _ws(_lib.lib.dram_norm_parts_ws_bytes(N, Co, nparts), dev)
         call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef), _p(rm), _p(rv),
              float(eaf), float(norm.eps), kind, groups, N, Co, S, _p(ws), ws.numel(), st)
     else:   # eval-mode BatchNorm: coefficients from the running statistics
-        HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
-                       "dram_conv3d_k3_fwd_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
-                       _p(skip.raw) if skip is not None else None, C2, _p(skip.coef) if skip is not None else None,
-                       int(skip.relu) if skip is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y), None,
-                       0, N, Co, D, H, W, st)
         call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
     out = Lazy(y, coef, relu=True)
     if record is not None and y.numel() * 4 < MATERIALISE_BELOW * torch.cuda.get_device_properties(dev).total_memory:
@@ -357,56 +391,80 @@ def backward(model, record, gout, need_dx):
                 grads[gamma] = dgamma
             if dbeta is not None:
                 grads[s.norm.bias] = dbeta
-            vox = N * S
-            # backward-weights: the x operand is the stage's lazy input(s); an upsampled input is produced again
-            inp = s.inp
-            up_tmp = inp.produce() if isinstance(inp, Upsampled) else None
-            if up_tmp is not None:
-                inp.kept = None                      # last use: released after this stage
-            x1 = Lazy(up_tmp) if up_tmp is not None else inp
-            skip = s.skip
-            dw = torch.empty_like(w)
-            wsb = _ws(_lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W), g.device)
-            name = HF.conv_wgrad_kernel_name((D, H, W), Co, Ci if skip is None else None,
-                                             lazy=(x1.coef is not None or (skip is not None and skip.coef is not None)))
+            inp, skip = s.inp, s.skip
+            up = isinstance(inp, Upsampled)
+            is_root = (not up) and inp is root
+            need_dgrad = skip is not None or not is_root or need_dx
+            ranges = _slices(inp, N) if up else [(0, N)]
+            whole = len(ranges) == 1
             lazy_ok = bool(_lib.lib.dram_conv3d_k3_wgrad_lazy_ok(N, C1, C2, Co, D, H, W)) and not _os.environ.get("DRAM_ENGINE_NO_LAZY_WGRAD")
-            if not lazy_ok:     # kernels without the on-load path (odd widths, first layer): plain operands
-                x1 = Lazy(x1.materialise())
-                skip_w = Lazy(skip.materialise()) if skip is not None else None
-            else:
-                skip_w = skip
-            HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
-                           "dram_conv3d_k3_wgrad_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
-                           _p(skip_w.raw) if skip_w is not None else None, C2,
-                           _p(skip_w.coef) if skip_w is not None else None, int(skip_w.relu) if skip_w is not None else 0,
-                           D2, H2, W2, oz, oy, ox, _p(g), _p(dw), _p(wsb), wsb.numel(), N, Co, D, H, W, st)
-            grads[w] = dw
-            del up_tmp, x1, skip_w
-            # backward-data: gradient w.r.t. the activated input(s)
-            is_root = (not isinstance(inp, Upsampled)) and inp is root
-            if skip is not None or not is_root or need_dx:
-                wt = HF._pack(w, 1)
-                dx1 = torch.empty((N, C1, D, H, W), dtype=torch.float32, device=g.device)
-                dx2 = None
-                if skip is not None:
-                    if id(skip) in gact:
-                        raise RuntimeError("fused backward: a skip tensor received a gradient before its up-path consumer")
-                    full = (D2, H2, W2) == (D, H, W)
-                    dx2 = torch.empty_like(skip.raw) if full else torch.zeros_like(skip.raw)
-                HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
-                               "dram_conv3d_k3_fwd_ex", _p(g), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
-                               _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
-                if skip is not None:
-                    gact[id(skip)] = dx2
-                if isinstance(inp, Upsampled):
-                    gact[("up", id(inp.src))] = dx1
+            dw = None
+            wt = HF._pack(w, 1) if need_dgrad else None
+            dx2 = None
+            if need_dgrad and skip is not None:
+                if id(skip) in gact:
+                    raise RuntimeError("fused backward: a skip tensor received a gradient before its up-path consumer")
+                full = (D2, H2, W2) == (D, H, W)
+                dx2 = torch.empty_like(skip.raw) if full else torch.zeros_like(skip.raw)
+            g_low = None        # gradient w.r.t. the low-resolution source of an upsampled input, filled slice by slice
+            if up and need_dgrad and not whole:
+                g_low = torch.empty_like(inp.src.raw)
+            for lo, hi in ranges:
+                n = hi - lo
+                vox = n * S
+                gs = g if whole else g[lo:hi]
+                # backward-weights: the x operand is the stage's lazy input(s); an upsampled input is produced again
+                if up:
+                    x1 = Lazy(inp.produce(lo, hi))
                 else:
-                    _accumulate(gact, id(inp), dx1)
+                    x1 = inp
+                sk = None if skip is None else (skip if whole else _lazy_slice(skip, lo, hi))
+                if not lazy_ok:     # kernels without the on-load path (odd widths, first layer): plain operands
+                    x1 = Lazy(x1.materialise())
+                    sk = Lazy(sk.materialise()) if sk is not None else None
+                dws = torch.empty_like(w)
+                wsb = _ws(_lib.lib.dram_conv3d_k3_wgrad_ws_bytes(n, Ci, Co, D, H, W), g.device)
+                name = HF.conv_wgrad_kernel_name((D, H, W), Co, Ci if skip is None else None,
+                                                 lazy=(x1.coef is not None or (sk is not None and sk.coef is not None)))
+                HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                               "dram_conv3d_k3_wgrad_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
+                               _p(sk.raw) if sk is not None else None, C2,
+                               _p(sk.coef) if sk is not None else None, int(sk.relu) if sk is not None else 0,
+                               D2, H2, W2, oz, oy, ox, _p(gs), _p(dws), _p(wsb), wsb.numel(), n, Co, D, H, W, st)
+                dw = dws if dw is None else dw.add_(dws)
+                del x1, sk, dws, wsb
+                # backward-data: gradient w.r.t. the activated input(s)
+                if need_dgrad:
+                    dx1 = torch.empty((n, C1, D, H, W), dtype=torch.float32, device=g.device)
+                    HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                                   "dram_conv3d_k3_fwd_ex", _p(gs), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
+                                   _p(dx1), C1, _p(dx2[lo:hi]) if dx2 is not None else None, C2, D2, H2, W2, oz, oy, ox,
+                                   n, D, H, W, st)
+                    if up and not whole:       # straight on to the low-resolution gradient: d(upsampled) is never whole
+                        g_low[lo:hi] = _trilinear_bwd(dx1, (n,) + tuple(inp.src.raw.shape[1:]))
+                    elif up:
+                        gact[("up", id(inp.src))] = dx1
+                    else:
+                        _accumulate(gact, id(inp), dx1)
+                    del dx1
+            if up:
+                inp.kept = None                  # last use of a kept upsampled tensor
+            if g_low is not None:
+                gact[("low", id(inp.src))] = g_low
+            if dx2 is not None:
+                gact[id(skip)] = dx2
+            grads[w] = dw
+            # this stage's tensors are dead from here on (its consumers ran their backward before it did)
+            s.y = s.coef = s.mean = s.rstd = None
+            s.out.raw = s.out.coef = None
             g = None
         elif tag == "up":
             lz, size = item[1], item[2]
-            gup = gact.pop(("up", id(lz)))
-            _accumulate(gact, id(lz), _trilinear_bwd(gup, tuple(lz.raw.shape)))
+            if ("low", id(lz)) in gact:      # the consumer stage ran in slices and already went through the resize
+                _accumulate(gact, id(lz), gact.pop(("low", id(lz))))
+            else:
+                gup = gact.pop(("up", id(lz)))
+                _accumulate(gact, id(lz), _trilinear_bwd(gup, tuple(lz.raw.shape)))
         elif tag == "pool":
             lz, idx, res = item[1], item[2], item[3]
             gp = gact.pop(id(res), None)

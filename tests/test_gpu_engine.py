@@ -146,3 +146,38 @@ def test_fused_stats_epilogue_extreme_mean():
     assert _rel(y, y64) <= 1e-5
     assert _rel(mean, m64) <= 1e-6
     assert _rel(rstd, 1.0 / torch.sqrt(v64 + 1e-5)) <= 1e-4   # sigma/mean ~ 1e-2: the variance keeps 4+ digits through y's fp32 rounding
+
+
+def test_fused_engine_sliced_and_fully_lazy(monkeypatch):
+    """The memory-saving modes that large batches switch on by themselves -- every activated tensor lazy, the upsampled
+    tensors never kept, upsampled-input stages executed in slices of ONE sample (statistics finalised once over all
+    slices, backward-weights summed over slices, the gradient of the upsampled tensor never whole) -- forced here on a
+    small batch: same step as the per-op path."""
+    import models
+    from dram_amd import engine
+    monkeypatch.setattr(engine, "MATERIALISE_BELOW", 0.0)
+    monkeypatch.setattr(engine, "KEEP_UPSAMPLED_BELOW", 0.0)
+    monkeypatch.setattr(engine, "SLICE_UPSAMPLED_ABOVE", 1e-12)
+    torch.manual_seed(7)
+    model = models.DC3D(**SLIM)
+    model.init(models.HeNorm(mode="fan_in"))
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(3.0 * torch.where(torch.arange(m.bias.numel()) % 3 == 2, -1.0, 1.0) * m.weight.abs())
+    model = model.to(DEV).train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    N, shape = 3, (16, 24, 16)
+    x = torch.rand((N, 1) + shape, generator=g).to(DEV)
+    gout = ((0.5 + torch.rand((N, 1) + shape, generator=g)) / x.numel()).to(DEV)
+    ref = _run(model, x, gout, False, True)
+    model.load_state_dict(sd0)
+    got = _run(model, x, gout, True, True)
+    assert _rel(got[0], ref[0]) <= 2e-5
+    worst = {k: _rel(got[1][k], ref[1][k]) for k in ref[1]}
+    assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-4}
+    assert _rel(got[2], ref[2]) <= 1e-4
+    for k, v in ref[3].items():
+        assert _rel(got[3][k].double(), v.double()) <= 1e-5, k
