@@ -11,9 +11,11 @@ A "step" is one optimisation step (forward + loss + backward + gradient all-redu
 reference's benchmark model `st_dram_ref.MODEL` (DC3D, BatchNorm, fp32; `checkpoint_layers` honoured in
 'stats' mode by default: no recomputation, the flagged blocks' double BatchNorm running-stat update is
 reproduced) on this rank's batch of synthetic lobe chunks: 64 chunks of 1x128^3 per GPU (the shape
-BASELINE.json's metric names), processed as gradient-accumulated micro-batches because 64x128^3 of
-saved activations does not fit 288 GB un-fused.  Inputs are resident in HBM before the
-timed region.  Weak scaling: the per-GPU batch is fixed.
+BASELINE.json's metric names), as ONE batch by default (BatchNorm statistics over all 64 chunks, like the
+reference): un-fused, 64x128^3 of saved activations does not fit 288 GB; the fused engine
+(dram_amd/engine.py) keeps the raw conv outputs only and peaks at 251 GB.  `--micro M` runs gradient-accumulated
+micro-batches of M chunks instead (M = 16: 123 GB, +0.7 % throughput, statistics per 16 chunks).  Inputs are
+resident in HBM before the timed region.  Weak scaling: the per-GPU batch is fixed.
 
 Rank 0 prints one JSON line: metric/value (whole-job voxels/s), roofline of the dominant kernel
 (3x3x3 conv as Winograd-F(2,3)-along-z implicit GEMMs on fp32 MFMA, timed live with HIP events), cpu_baseline (the oracle's
@@ -33,6 +35,7 @@ for _p in (ROOT, PKG):
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 dense peak
 PEAK_HBM_GBS = 8000.0
+PMC_MICRO = 64        # micro-batch of the rocprofv3 --pmc passes behind profiles/pmc_traffic.json (per-launch bytes scale with it)
 
 
 def wz_factor(kernel_name):
@@ -47,7 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=64, help="chunks per GPU per step (metric: 64)")
     ap.add_argument("--size", type=int, default=128, help="chunk edge (metric: 128)")
-    ap.add_argument("--micro", type=int, default=16, help="micro-batch (chunks) for gradient accumulation")
+    ap.add_argument("--micro", type=int, default=64, help="micro-batch (chunks): 64 = the whole per-GPU batch in one pass "
+                    "(BatchNorm statistics over all 64 chunks, like the reference); smaller = gradient accumulation")
     ap.add_argument("--norm", default="bn", help="norm_method of the model (reference default: bn)")
     ap.add_argument("--checkpoint-mode", default="stats", choices=["stats", "recompute"],
                     help="how checkpoint_layers flags are honoured (models.DC3D.checkpoint_mode)")
@@ -193,8 +197,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(batch, args.micro)
+    # Warm-up.  The 64-chunk batch goes through as ONE batch (the fused engine keeps raw conv outputs only and runs the
+    # widest stage in slices: 251 of 288 GB at its peak); should that not fit on this device (other tenants, a
+    # smaller part), fall back to gradient-accumulated micro-batches of half the size and say so in the output.
+    micro = min(args.micro, args.chunks)
+    if micro > 16:
+        args.warmup = max(args.warmup, 1)      # (the first step doubles as the "does it fit" probe)
+    for i in range(args.warmup):
+        while True:
+            try:
+                trainer.step(batch, micro)
+                break
+            except torch.OutOfMemoryError:
+                if micro <= 8:
+                    raise
+                opt.zero_grad(set_to_none=True)
+                torch.cuda.empty_cache()
+                micro //= 2
+                if rank == 0:
+                    print(f"bench.py: out of memory, retrying with micro-batch {micro}", file=sys.stderr, flush=True)
+    if world > 1:      # every rank must run the same micro-batch (same number of launches between barriers)
+        mt = torch.tensor([micro], device=dev)
+        dist.all_reduce(mt, op=dist.ReduceOp.MIN)
+        micro = int(mt.item())
+    args.micro = micro
     # per-kernel HIP events (one pair per conv launch, on the launch stream) ride along in the timed region
     use_timer = not args.no_kernel_timer
     sync()
@@ -246,7 +272,7 @@ def main():
                                 "direct-conv FLOPs of SURVEY 8(d) / time"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
             # (collected on micro-batches of 16 x 128^3: only that workload has the same launches)
-            if os.path.exists(pmc) and (args.size, min(args.micro, args.chunks)) == (128, 16):
+            if os.path.exists(pmc) and (args.size, args.chunks, args.micro) == (128, 64, PMC_MICRO):
                 try:
                     t = json.load(open(pmc)).get(dom)
                     if t:
@@ -269,6 +295,7 @@ def main():
         exec_ratio = tot_ex / tot_alg if tot_alg else (2.0 / 3.0)
         line = {
             "metric": "voxels/sec fwd+bwd (DC3D train step) on 64x128^3 CT chunks per GPU",
+            "batchnorm_statistics_over_chunks": args.micro,
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -266,10 +266,49 @@ def _bn_modules(block):
     return [m for m in block.modules() if isinstance(m, nn.BatchNorm3d)]
 
 
+# ------------------------------------------------------------------------------------------------ memory modes
+# "speed": activated outputs written (below MATERIALISE_BELOW), upsampled tensors kept (below KEEP_UPSAMPLED_BELOW);
+# "tight": the three thresholds at 2 % of the device memory -- everything large stays lazy, upsampled-input stages run in
+# slices.  "auto" (default) picks "tight" when writing everything would not fit: measured on the 64 x 128^3 benchmark,
+# "speed" peaks at 123 GB (micro-batch 16) / 195 GB (32), "tight" at 251 GB for all 64 chunks as ONE batch.
+MEMORY_MODE = _os.environ.get("DRAM_ENGINE_MEMORY", "auto")
+_SPEED = (MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE)
+_TIGHT = (0.02, 0.02, 0.02)
+
+
+def _raw_output_bytes(model, x):
+    """Bytes of all raw conv outputs of one forward (what the engine keeps at least)."""
+    vox = 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]
+    total, scale = 0.0, 1.0
+    for ds in model.ds_modules:
+        total += scale * sum(seq[0].out_channels for seq in ds.conv_blocks)
+        scale /= 8.0
+    total += scale * sum(seq[0].out_channels for seq in model.bg.conv_blocks)
+    for i, us in enumerate(model.us_modules or []):
+        if model.stacking == i:
+            break
+        scale *= 8.0
+        total += scale * sum(seq[0].out_channels for seq in us.conv_blocks)
+    return total * vox
+
+
+def _apply_memory_mode(model, x, training):
+    global MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE
+    mode = MEMORY_MODE
+    if mode == "auto":
+        cap = torch.cuda.get_device_properties(x.device).total_memory
+        # the written activations and kept upsampled tensors add ~1.2x the raw outputs on top of them
+        mode = "tight" if training and 2.2 * _raw_output_bytes(model, x) > 0.62 * cap else "speed"
+    MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE = _TIGHT if mode == "tight" else _SPEED
+    return mode
+
+
 def forward(model, x, record):
     """DC3D.forward (models.py:120-147) on lazy tensors.  `record`: list that receives the tape for backward, or None
     (inference).  Returns the dense output [N, out_ch, D, H, W]."""
     training = model.training
+    if MEMORY_MODE in ("auto", "speed", "tight"):        # ("manual": the three thresholds as set by the caller)
+        _apply_memory_mode(model, x, record is not None)
     L = model.n_layers
     x = HF._chk(x, "DC3D input", 5)
     grad_flows = record is not None          # the reference re-runs a checkpointed block in backward only then

@@ -32,11 +32,11 @@ def collect(path, counter, scale):
 def main():
     fetch = collect(sys.argv[1], "FETCH_SIZE", 2.0)
     write = collect(sys.argv[2], "WRITE_SIZE", 1.0)
-    out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --chunks 16 "
-                      "--micro 16 --steps 1 --warmup 0` (one micro-batch = the same launches as the full bench); "
+    out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
+                      "--warmup 1` (the default workload: 64 chunks of 128^3 as one batch, two steps; scripts/profile_round.sh); "
                       "counters are in KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                       "requests at 64 B) -- confirmed by scripts/pmc_calibrate.py; aggregated by scripts/pmc_aggregate.py",
-           "_unit": "HBM bytes per launch (average over the launches of that kernel in one micro-batch)"}
+           "_unit": "HBM bytes per launch (average over the launches of that kernel in the run)"}
     for k in sorted(set(fetch) | set(write)):
         if "at::" in k or k.startswith("void ") or k.startswith("__amd") or "_kernel" not in k or "elementwise" in k \
                 or k.startswith("direct_copy"):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats of the default bench, then the two PMC passes
-# (FETCH_SIZE, WRITE_SIZE -- separate runs, counters only) over one micro-batch of the same workload.
+# (FETCH_SIZE, WRITE_SIZE -- separate runs, counters only) over two steps of the same workload (default bench: the
+# 64 chunks as one batch).
 #   gpurun -- 'bash scripts/profile_round.sh r01_d'
 # Results land in gpurun_out/<tag>/ ; copy the summaries into profiles/ (see scripts/pmc_aggregate.py).
 set -eo pipefail
@@ -10,9 +11,9 @@ O=gpurun_out/$TAG
 mkdir -p "$O"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- \
     python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt.err"
-timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- \
-    python3 bench.py --chunks 16 --micro 16 --steps 1 --warmup 0 --no-cpu-baseline > "$O/f.out" 2> "$O/f.err"
-timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- \
-    python3 bench.py --chunks 16 --micro 16 --steps 1 --warmup 0 --no-cpu-baseline > "$O/w.out" 2> "$O/w.err"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- \
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > "$O/f.out" 2> "$O/f.err"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- \
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > "$O/w.out" 2> "$O/w.err"
 find "$O" -name "*kernel_trace.csv" -delete     # per-dispatch trace: large, the stats CSV is what is kept
 find "$O" -name "*.csv" | xargs ls -la

@@ -155,6 +155,7 @@ def test_fused_engine_sliced_and_fully_lazy(monkeypatch):
     small batch: same step as the per-op path."""
     import models
     from dram_amd import engine
+    monkeypatch.setattr(engine, "MEMORY_MODE", "manual")
     monkeypatch.setattr(engine, "MATERIALISE_BELOW", 0.0)
     monkeypatch.setattr(engine, "KEEP_UPSAMPLED_BELOW", 0.0)
     monkeypatch.setattr(engine, "SLICE_UPSAMPLED_ABOVE", 1e-12)
