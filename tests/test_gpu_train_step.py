@@ -90,7 +90,7 @@ def test_trainer_step_matches_oracle(golden_dir):
     dense = out[0] if isinstance(out, (tuple, list)) else out
     reg_r, seg_r = O.int_reg_refine_loss(dense, lobes.double(), lesions.double(), ctss, FREQ, 1e-2, 0.1)
     (2.0 * reg_r + seg_r).backward()
-    lr = 1e-3
+    lr = 0.5      # a step of the size of the gradient: the fp32 rounding of w - lr*g (ulp(w)/2 ~ 4e-9) stays far below it
     expect = {k: (p.detach() - lr * p.grad).float() for k, p in params.items()}
     for micro in (None, 3):
         m.load_state_dict(sd)
@@ -105,7 +105,7 @@ def test_trainer_step_matches_oracle(golden_dir):
             for k, e in expect.items():
                 step_ref = (e - sd[k]).abs().max().item()
                 err = (got[k] - e).abs().max().item()
-                assert err <= 2e-2 * step_ref + 1e-9, (k, err, step_ref)
+                assert err <= 2e-3 * step_ref + 1e-9, (k, err, step_ref)
         m = m.cpu()
 
 
