@@ -407,6 +407,71 @@ __global__ __launch_bounds__(256) void crop_concat_bwd2_kernel(const float* __re
     dt2[plane * (int64_t)S2 + e] = v;
 }
 
+
+// ---------------------------------------------------------------- Rotate3DXOneShot (data_transforms.py:1186-1208)
+// F.grid_sample(x, F.affine_grid(theta, x.size())) with the defaults the reference relies on (bilinear = trilinear for
+// 5-D, zeros padding, align_corners=False), theta [3][4] the same for every sample: output voxel (d,h,w) has the
+// normalised coordinates xn = (2w+1)/W - 1, yn, zn; the source point is theta @ (xn, yn, zn, 1) = (gx, gy, gz) (x <-> W,
+// y <-> H, z <-> D), un-normalised as ix = ((gx + 1) * W - 1) / 2; eight taps, those outside the volume contribute 0.
+struct Affine34 {
+    float m[12];
+};
+__device__ __forceinline__ void affine_source(const Affine34& t, int D, int H, int W, int d, int h, int w, float& iz, float& iy,
+                                              float& ix) {
+    const float xn = (2.f * (float)w + 1.f) / (float)W - 1.f;
+    const float yn = (2.f * (float)h + 1.f) / (float)H - 1.f;
+    const float zn = (2.f * (float)d + 1.f) / (float)D - 1.f;
+    const float gx = t.m[0] * xn + t.m[1] * yn + t.m[2] * zn + t.m[3];
+    const float gy = t.m[4] * xn + t.m[5] * yn + t.m[6] * zn + t.m[7];
+    const float gz = t.m[8] * xn + t.m[9] * yn + t.m[10] * zn + t.m[11];
+    ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    iz = ((gz + 1.f) * (float)D - 1.f) * 0.5f;
+}
+// BWD = false: y[plane][e] = sum over taps; BWD = true: dx[plane][tap] += w * dy[plane][e] (float atomics: the scatter
+// form of the adjoint; the order of the additions, and with it the last bits, is not fixed -- as in ATen's backward)
+template <bool BWD>
+__global__ __launch_bounds__(256) void affine_sample_kernel(const float* __restrict__ src, float* dst, Affine34 t, int D, int H,
+                                                            int W, int planes) {
+    const int S = D * H * W;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S) return;
+    const int w = e % W, h = (e / W) % H, d = e / (W * H);
+    float iz, iy, ix;
+    affine_source(t, D, H, W, d, h, w, iz, iy, ix);
+    const float fz = floorf(iz), fy = floorf(iy), fx = floorf(ix);
+    const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+    const float lz = iz - fz, ly = iy - fy, lx = ix - fx;
+    int off[8];
+    float wt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zz = z0 + (k >> 2), yy = y0 + ((k >> 1) & 1), xx = x0 + (k & 1);
+        const bool in = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[k] = in ? (zz * H + yy) * W + xx : -1;
+        wt[k] = ((k >> 2) ? lz : 1.f - lz) * (((k >> 1) & 1) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+    }
+    const int p0 = blockIdx.y * TRI_CPT;
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        if (!BWD) {
+            const float* p = src + (int64_t)plane * S;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (off[k] >= 0) acc += wt[k] * p[off[k]];
+            dst[(int64_t)plane * S + e] = acc;
+        } else {
+            const float g = src[(int64_t)plane * S + e];
+            float* p = dst + (int64_t)plane * S;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (off[k] >= 0) atomicAdd(p + off[k], wt[k] * g);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- OneShot transforms
 // F.interpolate(mode='nearest'): src = min(floor(dst * scale), in-1), scale = in/out (ATen nearest_neighbor_compute_source_index)
 __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H,
@@ -722,4 +787,32 @@ extern "C" int dram_spatial_permute_flip(const float* x, float* y, int N, int C,
     for (int k = 0; k < 3; ++k) { p.od[k] = id[perm[k]]; p.perm[k] = perm[k]; p.flip[k] = flip[k] ? 1 : 0; }
     hipLaunchKernelGGL(permute_flip_kernel, dim3(cdiv(D * H * W, 256), N * C), dim3(256), 0, (hipStream_t)stream, x, y, p);
     return check_launch("spatial_permute_flip");
+}
+
+extern "C" int dram_affine_sample_fwd(const float* x, float* y, const float* theta12, int N, int C, int D, int H, int W,
+                                      void* stream) {
+    DRAM_REQUIRE(x && y && theta12, "affine_sample_fwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0, "affine_sample_fwd: bad sizes");
+    int rc = check_planes("affine_sample_fwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    Affine34 t;
+    for (int i = 0; i < 12; ++i) t.m[i] = theta12[i];
+    hipLaunchKernelGGL(affine_sample_kernel<false>, dim3(cdiv(D * H * W, 256), cdiv(N * C, TRI_CPT)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, t, D, H, W, N * C);
+    return check_launch("affine_sample_fwd");
+}
+
+extern "C" int dram_affine_sample_bwd(const float* dy, float* dx, const float* theta12, int N, int C, int D, int H, int W,
+                                      void* stream) {
+    DRAM_REQUIRE(dy && dx && theta12, "affine_sample_bwd: null pointer");
+    DRAM_REQUIRE(D > 0 && H > 0 && W > 0, "affine_sample_bwd: bad sizes");
+    int rc = check_planes("affine_sample_bwd", (int64_t)N * C, (int64_t)D * H * W);
+    if (rc) return rc;
+    Affine34 t;
+    for (int i = 0; i < 12; ++i) t.m[i] = theta12[i];
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(dx, 0, (size_t)N * C * D * H * W * sizeof(float), st);
+    hipLaunchKernelGGL(affine_sample_kernel<true>, dim3(cdiv(D * H * W, 256), cdiv(N * C, TRI_CPT)), dim3(256), 0, st, dy, dx, t,
+                       D, H, W, N * C);
+    return check_launch("affine_sample_bwd");
 }

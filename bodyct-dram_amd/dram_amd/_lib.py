@@ -97,6 +97,8 @@ SIGNATURES = {
     "dram_masked_smooth_l1_ws_bytes": (Z, [I, I, L]),
     "dram_masked_smooth_l1_fwd": (I, [P, P, P, P, P, Z, I, I, L, P]),
     "dram_masked_smooth_l1_bwd": (I, [P, P, P, P, P, P, P, I, I, L, P]),
+    "dram_affine_sample_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "dram_affine_sample_bwd": (I, [P, P, P, I, I, I, I, I, P]),
 }
 
 

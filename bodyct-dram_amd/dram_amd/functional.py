@@ -859,6 +859,35 @@ def interpolate_nearest(x, size=None, scale_factor=None):
     return y
 
 
+class AffineSampleFn(Function):
+    """F.grid_sample(x, F.affine_grid(theta, x.size())) for one [3,4] theta shared by the batch
+    (Rotate3DXOneShot, reference data_transforms.py:1186-1208)."""
+
+    @staticmethod
+    def forward(ctx, x, theta):
+        x = _chk(x, "affine sample input", 5)
+        N, C, D, H, W = x.shape
+        arr = (ctypes.c_float * 12)(*[float(v) for v in theta])
+        y = torch.empty_like(x)
+        call("dram_affine_sample_fwd", _p(x), _p(y), arr, N, C, D, H, W, _stream())
+        ctx.theta = tuple(float(v) for v in theta)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _chk(dy, "affine sample grad_output", 5)
+        N, C, D, H, W = dy.shape
+        arr = (ctypes.c_float * 12)(*ctx.theta)
+        dx = torch.empty_like(dy)
+        call("dram_affine_sample_bwd", _p(dy), _p(dx), arr, N, C, D, H, W, _stream())
+        return dx, None
+
+
+def affine_sample(x, theta12):
+    return AffineSampleFn.apply(x, tuple(theta12))
+
+
 class SpatialPermuteFlipFn(Function):
     """A signed permutation of the spatial axes of [N,C,D,H,W] (torch.flip / torch.rot90 / transpose chains)."""
 

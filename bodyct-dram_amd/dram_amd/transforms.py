@@ -8,7 +8,7 @@ interpolation when rescaling.  The classes here keep those names, constructor ar
 (same `random` / `numpy.random` calls in the same order), but run on the gather kernels of csrc/resample.hip instead
 of torch.flip / torch.rot90 / F.interpolate, and stay differentiable where the reference's are (the loss transforms the
 predicted probabilities).  `Rotate3DXOneShot` (affine_grid + grid_sample; commented out of the reference's transform
-pool) is not provided."""
+pool) is one gather kernel with a scatter adjoint."""
 import itertools
 import random
 
@@ -76,6 +76,25 @@ class Rotate903DOneShot(_OneShot):
             raise AssertionError("Rotate903DOneShot expects [N,C,D,H,W] tensors")
         ops = HF.rot90_ops(self.rotate_times, tuple(a % 5 for a in self.rotate_axis))
         return HF.spatial_permute_flip(tensor, *HF.signed_permutation(ops))
+
+
+class Rotate3DXOneShot(_OneShot):
+    """Rotation by `theta` (radians; without an argument one np.random.uniform draw from the given range, as the
+    reference does) about the x axis of the normalised grid: F.affine_grid + F.grid_sample with their defaults
+    (trilinear, zeros padding, align_corners=False), data_transforms.py:1186-1208."""
+
+    def __init__(self, theta=(0, np.pi)):
+        self.theta = np.random.uniform(theta[0], theta[1], 1)
+
+    def get_rot_mat(self):
+        # (the reference evaluates cos / sin in float64 and casts the matrix to the data type)
+        c, s = float(np.float32(np.cos(self.theta[0]))), float(np.float32(np.sin(self.theta[0])))
+        return [1.0, 0.0, 0.0, 0.0, 0.0, c, -s, 0.0, 0.0, s, c, 0.0]
+
+    def _transform(self, key, tensor):
+        if tensor.dim() != 5:
+            raise AssertionError("Rotate3DXOneShot expects [N,C,D,H,W] tensors")
+        return HF.affine_sample(tensor, self.get_rot_mat())
 
 
 class Rescale3DOneShot(_OneShot):

@@ -373,6 +373,14 @@ int dram_masked_smooth_l1_fwd(const float* a, const float* b, const float* mask,
 int dram_masked_smooth_l1_bwd(const float* a, const float* b, const float* mask, const float* out,
                               const float* gout, float* da, float* db, int N, int C, int64_t S, void* stream);
 
+/* Rotate3DXOneShot (data_transforms.py:1186-1208): F.grid_sample(x, F.affine_grid(theta, x.size())) with the defaults
+ * (trilinear, zeros padding, align_corners=False); theta12 = HOST pointer to the row-major [3][4] matrix shared by all
+ * samples.  Backward = the scatter adjoint (float atomics: summation order not fixed, like ATen's). */
+int dram_affine_sample_fwd(const float* x, float* y, const float* theta12, int N, int C, int D, int H, int W,
+                           void* stream);
+int dram_affine_sample_bwd(const float* dy, float* dx, const float* theta12, int N, int C, int D, int H, int W,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,6 +306,18 @@ def gen_transforms():
         (out * go).sum().backward()
         arrs[f"rs/{i}/mode"], arrs[f"rs/{i}/sf"] = np.array(0 if mode == "size" else 1), np.array(sf, dtype=np.float64)
         arrs[f"rs/{i}/out"], arrs[f"rs/{i}/gout"], arrs[f"rs/{i}/gin"], arrs[f"rs/{i}/lab"] = _np(out), _np(go), _np(xi.grad), _np(outl)
+    # Rotate3DXOneShot (affine_grid + grid_sample; commented out of the reference's pool, but the class is there)
+    for i, th in enumerate((0.3, 1.1, 2.6)):
+        t = DT.Rotate3DXOneShot()
+        t.theta = np.array([th])
+        xi = x.clone().requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = t({"#image": xi})["#image"]
+        go = torch.randn(out.shape, generator=g)
+        (out * go).sum().backward()
+        arrs[f"rx/{i}/theta"] = np.array(th)
+        arrs[f"rx/{i}/out"], arrs[f"rx/{i}/gout"], arrs[f"rx/{i}/gin"] = _np(out), _np(go), _np(xi.grad)
     _save("transforms", **arrs)
 
 

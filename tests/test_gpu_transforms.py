@@ -67,3 +67,22 @@ def test_random_parameter_choice_and_protocol():
     with pytest.raises(NotImplementedError):
         s({"#other": x})
     assert T.Identity()({"a": 1}) == {"a": 1}
+
+
+def test_rotate3dx_matches_reference(golden_dir):
+    """Rotate3DXOneShot (affine_grid + grid_sample with their defaults) against the reference's class at three angles:
+    output and the gradient w.r.t. the input (scatter adjoint through float atomics) at 1e-5."""
+    from dram_amd import transforms as T
+    z = np.load(os.path.join(golden_dir, "transforms.npz"))
+    n = len([k for k in z.files if k.startswith("rx/") and k.endswith("/theta")])
+    assert n == 3
+    for i in range(n):
+        t = T.Rotate3DXOneShot()
+        t.theta = np.array([float(z[f"rx/{i}/theta"])])
+        x = torch.from_numpy(z["x"]).cuda().requires_grad_(True)
+        out = t({"#image": x})["#image"]
+        _close(out, z[f"rx/{i}/out"], 1e-5)
+        (out * torch.from_numpy(z[f"rx/{i}/gout"]).cuda()).sum().backward()
+        _close(x.grad, z[f"rx/{i}/gin"], 1e-5)
+    np.random.seed(4)
+    assert 0.0 <= float(T.Rotate3DXOneShot().theta[0]) <= np.pi
