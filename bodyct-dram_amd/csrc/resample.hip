@@ -334,6 +334,60 @@ __global__ __launch_bounds__(256) void trilinear_bwd_z_kernel(const float* __res
     }
 }
 
+// Stage 2 of the two-stage adjoint with 16-byte rows: a thread owns FOUR consecutive inputs xi0..xi0+3 of one (z, y)
+// row.  For magnifications between 1x and 2.2x along x (0.4545 <= scale <= 1) every output that touches them lies in
+// the 16 outputs [base, base + 15], base = (first touching output - 1) rounded down to a multiple of 4: per y tap ONE
+// row segment of four aligned 16-byte loads feeds all four inputs through a dense 4 x 16 weight table (computed once
+// per thread with the same touch_weight as the gather kernel; zeros where an output does not touch an input) -- 4
+// loads per input and y tap instead of ~3 scalar ones per (input, x tap).
+__global__ __launch_bounds__(256) void trilinear_bwd_yx4_kernel(const float* __restrict__ tmp, float* __restrict__ dx, int D,
+                                                                Axis ay, Axis ax, int planes) {
+    const int W4 = ax.in >> 2;
+    const int per_plane4 = D * ay.in * W4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_plane4) return;
+    const int x4 = e % W4, yi = (e / W4) % ay.in, zi = e / (W4 * ay.in);
+    const int xi0 = 4 * x4;
+    int base = 0;
+    if (xi0 >= 1) {
+        base = (int)ceilf((float)(xi0 - 1) / ax.scale) - 2;      // one below the first output with floor(scale*o) >= xi0-1, and one for rounding
+        base = base < 0 ? 0 : base & ~3;
+    }
+    float wx[4][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) wx[j][m] = (base + m) < ax.out ? touch_weight(ax, base + m, xi0 + j) : 0.f;
+    const Taps ty = axis_taps(ay, yi);
+    const int Ho = ay.out, Wo = ax.out;
+    const int64_t St = (int64_t)D * Ho * Wo, S = (int64_t)D * ay.in * ax.in;
+    const int p0 = blockIdx.y * TRI_CPT;
+    for (int u = 0; u < TRI_CPT; ++u) {
+        const int plane = p0 + u;
+        if (plane >= planes) break;
+        const float* p = tmp + (int64_t)plane * St + ((int64_t)zi * Ho + ty.lo) * Wo + base;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < ty.n; ++ky) {
+            const float* row = p + (int64_t)ky * Wo;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {       // (a 16-byte piece beyond the row end is not read: its weights are 0)
+                const float4 t = (base + 4 * q) < Wo ? *reinterpret_cast<const float4*>(row + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            const float wy = ty.w[ky];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = 0.f;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) r = fmaf(wx[j][m], v[m], r);
+                acc[j] = fmaf(wy, r, acc[j]);
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (int64_t)plane * S + 4 * (int64_t)e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // general fallback (any magnification): plane per blockIdx.y, weights recomputed inside the loops
 __global__ __launch_bounds__(256) void trilinear_bwd_general_kernel(const float* __restrict__ dy,
                                                                     float* __restrict__ dx, Axis az, Axis ay, Axis ax) {
@@ -659,8 +713,12 @@ extern "C" int dram_upsample_trilinear_ac_bwd_ws(const float* dy, float* dx, voi
         const int g = (int)((planes - p0) < group ? (planes - p0) : group);
         hipLaunchKernelGGL(trilinear_bwd_z_kernel, dim3(cdiv(D * Ho * (Wo / 4), 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
                            dy + p0 * So, (float*)ws, az, Ho, Wo, g);
-        hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(cdiv(D * H * W, 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
-                           (const float*)ws, dx + p0 * S, idz, ay, ax, g);
+        if (ax.scale >= 0.4546f && ax.scale <= 1.f && (W % 4) == 0 && ((((uintptr_t)(dx + p0 * S)) & 15) == 0))
+            hipLaunchKernelGGL(trilinear_bwd_yx4_kernel, dim3(cdiv(D * H * (W / 4), 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
+                               (const float*)ws, dx + p0 * S, D, ay, ax, g);
+        else
+            hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(cdiv(D * H * W, 256), cdiv(g, TRI_CPT)), dim3(256), 0, st,
+                               (const float*)ws, dx + p0 * S, idz, ay, ax, g);
     }
     return check_launch("upsample_trilinear_ac_bwd(two-stage)");
 }
