@@ -183,3 +183,23 @@ def test_one_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[0] == "1", out.stdout
+
+
+def test_engine_applicability_and_footprint():
+    """Host logic of the fused engine (dram_amd/engine.py) that needs no device: which networks it covers (the others
+    take the per-op path), and the raw-output footprint that picks its memory mode."""
+    import models
+    from dram_amd import engine
+    from dram_amd.configs import SLIM, ST_DRAM_REF_MODEL
+    assert engine.supports(models.DC3D(**SLIM))
+    for norm in ("bnt", "bntna", "ln", "lnna", "in"):
+        assert engine.supports(models.DC3D(**SLIM, norm_method=norm)), norm
+    assert not engine.supports(models.DC3D(**SLIM, norm_method="sbn"))         # cross-rank statistics: per-op path
+    assert not engine.supports(models.DC3D(**SLIM, norm_method=None))          # no norm (and conv biases)
+    assert not engine.supports(models.DC3D(**SLIM, act_method="prelu"))
+    assert not engine.supports(models.DC3D(**dict(SLIM, dropout=0.1)))
+    full = models.DC3D(**ST_DRAM_REF_MODEL)
+    gib = lambda n: engine._raw_output_bytes(full, torch.empty(n, 1, 128, 128, 128, device="meta")) / 2 ** 30
+    # 295.5 channel-planes at full resolution per sample: 32+64 | (64+128)/8 | (128+256)/64 | (256+512)/512 | 512/64 | 256/8 | 128
+    assert abs(gib(1) - 295.5 * 128 ** 3 * 4 / 2 ** 30) < 1e-6
+    assert 2.2 * gib(32) < 0.62 * 288 < 2.2 * gib(64)        # "speed" up to 32 chunks, "tight" for the whole batch of 64
