@@ -708,6 +708,295 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / backward-data with Winograd F(2x2, 3x3) over (z, y) -- exact fp32 arithmetic, 4/9 of the direct MFMAs
+// (2/3 of the z-only kernel's).
+//
+// A 2x2 (z,y) group of outputs and its 4x4 input patch d (per x and ci; the three x taps stay direct):
+//     V = B^T d B,   U_kx = G g[:,:,kx] G^T,   M += U_kx (.) V(x + kx),   Y = A^T M A
+// with the 1-D matrices of the z-only kernel applied along both axes (constants 0, +-1, 1/2; 1/4 in U).  In GEMM terms:
+// 16 independent implicit GEMMs (one per transformed element xi = 4 xi_z + xi_y) with K = Cin x 3 x-taps, N = the
+// positions (x, y pair) of a plane pair; 16 products per (ci, kx) instead of 36 for 4 outputs.
+//
+// The 16 accumulator tiles of a 32-position x 32-channel tile are 256 registers -- a whole register file half.  Two
+// waves share such a tile instead: one holds xi_z = 0,1, the other xi_z = 2,3 (128 accumulator registers each, two
+// waves per SIMD as in the other kernels); in the epilogue each applies the y part of A^T to its rows, the two swap
+// one intermediate row pair through LDS and each finishes ONE output plane (so a wave again ends with 32 positions x
+// 2 rows x 32 channels, the shape the statistics epilogue and the stores of the z-only kernel work on).
+//
+// Block = 512 threads = 32 x positions x 2 y pairs x 1 z pair (256 voxels) x 64 output channels:
+// wave = (y pair, 32-channel tile, xi_z half); one block per CU (133 KB of LDS: inputs AND filters double-buffered,
+// one barrier per chunk).  What a second resident block covers in the other kernels is scheduled by hand here: the
+// next chunk's global loads are issued at the top of a chunk, its input transform and LDS stores are sliced into the
+// MFMA loop, and LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest
+// LDS axis) one iteration ahead of their MFMAs.
+// Staging: wave w owns channel c0 + (w & 3) of the chunk; in waves 0-3 a lane = (y pair, x < 32) transforms one 4x4
+// patch (16 loads, 32 adds, 16 stores); waves 4-7 do the same for the two extra halo columns (4 lanes).
+// Filters: wzy[t = 16 kx + xi][chunk][kh][Cout][kk] (channel = 4 chunk + 2 kk + kh), zero-filled to whole chunks by
+// pack_weights_wzy_kernel, so that a chunk's [48][2][64][2] tile is copied with 16-byte loads and stores.
+// Serves Cout % 64 == 0, Cin >= 8, volumes that 32x4x2 boxes cover well (fwd_choice); everything else: the z-only kernel.
+struct FwdWzyGeom {
+    static constexpr int HX = 34;
+    static constexpr int XI_STRIDE = 2 * HX * 2;        // floats per transformed plane: [y pair][hx][kk]
+    static constexpr int KH_STRIDE = 16 * XI_STRIDE;    // per channel parity kh
+    static constexpr int IN_STAGE = 2 * KH_STRIDE;      // 4352 floats
+    static constexpr int WT_STRIDE = 2 * 64 * 2;        // per filter matrix t: [kh][co][kk]
+    static constexpr int W_STAGE = 48 * WT_STRIDE;      // 12288 floats
+    static constexpr int WPASS = W_STAGE / 4 / 512;     // 16-byte slots per thread and chunk
+    static constexpr size_t LDS_BYTES = (size_t)2 * (IN_STAGE + W_STAGE) * sizeof(float);
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool FUSED = false>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a) {
+    using G = FwdWzyGeom;
+    constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
+    constexpr int WTS = G::WT_STRIDE, W_STAGE = G::W_STAGE, WPASS = G::WPASS;
+    static_assert(8 * 32 * 64 * sizeof(float) <= G::LDS_BYTES, "epilogue exchange fits the (dead) stages");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const lw0 = lds + 2 * IN_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, 64-channel tile), channel tile fastest
+    const int co0 = (b % a.co_tiles) * 64; b /= a.co_tiles;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    const int n = b / a.nbz;
+    const int x0 = bx * 32, y0 = by * 4, z0 = bz * 2;
+    const int D = a.D, H = a.H, W = a.W;
+    const int S = D * H * W;
+    const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
+
+    // ---- staging role: channel c0 + (wave & 3); waves 0-3: lane = (y pair, hx < 32); waves 4-7: lanes 0..3 = (y pair, hx = 32, 33) ----
+    const int s_ci = wave & 3, s_kk = s_ci >> 1, s_kh = s_ci & 1;
+    unsigned off1[4], off2[4];     // in-plane byte offsets of the patch rows in source 1 / 2 (OOB: outside, or no item)
+    int st_idx;                    // LDS float index of this item's xi = 0 element
+    bool st_ok;
+    {
+        const bool extra = wave >= 4;
+        const int i_ty = extra ? (lane >> 1) & 1 : lane >> 5;
+        const int i_hx = extra ? 32 + (lane & 1) : lane & 31;
+        st_ok = !extra || lane < 4;
+        const int gx = x0 - 1 + i_hx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 - 1 + 2 * i_ty + r;
+            const bool ok = st_ok && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            off1[r] = ok ? 4u * (unsigned)(gy * W + gx) : OOB;
+            off2[r] = ok ? 4u * (unsigned)((gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
+        }
+        st_idx = s_kh * KHS + (i_ty * HX + i_hx) * 2 + s_kk;
+    }
+    bool zok[4];
+    unsigned zoff1[4], zoff2[4];   // plane byte offsets (wave-uniform: the scalar offset of the loads)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int gz = z0 - 1 + q;
+        zok[q] = gz >= 0 && gz < D;
+        zoff1[q] = zok[q] ? 4u * (unsigned)(gz * H * W) : 0u;
+        zoff2[q] = zok[q] ? 4u * (unsigned)((gz + a.src.oz) * a.src.H2 * a.src.W2) : 0u;
+    }
+    const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
+    const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
+
+    // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
+    const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
+    const int j = lane & 31, kh = lane >> 5;
+    const int bbase = kh * KHS + 8 * xh * XI + (ty * HX + j) * 2;
+    const int abase = 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // filters: slot f = p*512 + tid of the chunk's [48][2][64][2] tile <- wzy[t][chunk][kh][Cout][kk], copied by
+    // direct-to-LDS loads (no registers, no ds_write: the tile is lane-linear per wave-instruction)
+    const int nchunk = (a.Cin + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 48u * 16u * (unsigned)nchunk * (unsigned)a.Cout);
+    unsigned wvoff;                 // slot 0; slot p is 8 filter matrices further
+    {
+        const int t = tid >> 6, r = tid & 63;
+        const int wkh = r >> 5, q4 = r & 31;
+        wvoff = 4u * (unsigned)(((t * nchunk) * 2 + wkh) * a.Cout * 2 + co0 * 2 + 4 * q4);
+    }
+    const unsigned wchunk_bytes = 16u * (unsigned)a.Cout;
+    const unsigned wpass_bytes = 8u * (unsigned)nchunk * wchunk_bytes;
+
+    float rin[4][4];               // prefetched raw patch [z plane q][row r] of the next chunk
+    const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);
+    LazyCoef lc;
+
+    auto load_chunk = [&](int c0, float* nw) {
+        const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nw + 4 * (p * 512 + 64 * wave)), 16, (int)wvoff,
+                                                 (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
+        const int ci = c0 + s_ci;                        // wave-uniform
+        const bool first = ci < a.src.C1;
+        const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
+        const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;
+        const float* up = uniform_ptr(plane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok[q] ? bytes : 0u);   // a plane outside the volume: all zeros
+            const unsigned so = first ? zoff1[q] : zoff2[q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
+        }
+        if (lazy) lc = lazy_coef(a, n, ci);
+    };
+    // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor
+    auto activate = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rin[q][r] = (zok[q] && off1[r] != OOB) ? fmaxf(fmaf(lc.a, rin[q][r], lc.b), lc.lo) : 0.f;
+    };
+    auto transform_z = [&]() {                           // B^T d along z (in place)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d0 = rin[0][r], d1 = rin[1][r], d2 = rin[2][r], d3 = rin[3][r];
+            rin[0][r] = d0 - d2; rin[1][r] = d1 + d2; rin[2][r] = d2 - d1; rin[3][r] = d1 - d3;
+        }
+    };
+    auto transform_y_store = [&](float* o, int q) {      // (.) B along y, row xi_z = q -> LDS
+        if (st_ok) {
+            const float d0 = rin[q][0], d1 = rin[q][1], d2 = rin[q][2], d3 = rin[q][3];
+            o[(4 * q + 0) * XI] = d0 - d2;
+            o[(4 * q + 1) * XI] = d1 + d2;
+            o[(4 * q + 2) * XI] = d2 - d1;
+            o[(4 * q + 3) * XI] = d1 - d3;
+        }
+    };
+    // One chunk of MFMAs out of stage (lin, lw); with stage_next the staging of the prefetched chunk into (nin, nw) is
+    // sliced between the iterations.  12 iterations of 2 (kx, xi) steps x 2 k-steps = 4 MFMAs, operands one iteration ahead.
+    auto compute = [&](const float* lin, const float* lw, float* nin, bool stage_next) {
+        f32x2 av[2][2], bv[2][2];
+#pragma unroll
+        for (int it = 0; it <= 12; ++it) {
+            if (it < 12) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
+                    av[it & 1][h] = *reinterpret_cast<const f32x2*>(lw + abase + (16 * kx + xi) * WTS);
+                    bv[it & 1][h] = *reinterpret_cast<const f32x2*>(lin + bbase + xi * XI + 2 * kx);
+                }
+            }
+            if (it > 0) {
+                const int i0 = it - 1;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int xi = (2 * i0 + h) & 7;
+                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
+                    }
+            }
+            if (it >= 5 && it < 11 && stage_next) {      // (block-uniform)
+                if (it == 5 && lazy) activate();
+                if (it == 6) transform_z();
+                if (it >= 7 && it < 11) transform_y_store(nin + st_idx, it - 7);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: chunk 0 straight into stage 0
+    load_chunk(0, lw0);
+    {
+        if (lazy) activate();
+        transform_z();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
+        const bool has_next = (c0 + 4) < a.Cin;
+        const float* lin = lds + cur * IN_STAGE;
+        const float* lw = lw0 + cur * W_STAGE;
+        float* nin = lds + (cur ^ 1) * IN_STAGE;
+        float* nw = lw0 + (cur ^ 1) * W_STAGE;
+        if (has_next) load_chunk(c0 + 4, nw);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(lin, lw, nin, has_next);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----
+    // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
+    float pq[2][2][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pq[q][0][r] = (acc[4 * q][r] + acc[4 * q + 1][r]) + acc[4 * q + 2][r];
+            pq[q][1][r] = (acc[4 * q + 1][r] - acc[4 * q + 2][r]) - acc[4 * q + 3][r];
+        }
+    // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
+    // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1: swap them through LDS (the stages are dead: the loop's
+    // last barrier is behind every read).  Slot layout [wave][register][lane]: conflict-free.
+    {
+        float* mine = lds + (size_t)wave * 32 * 64 + lane;
+        const float* theirs = lds + (size_t)(wave ^ 4) * 32 * 64 + lane;
+        const int send = xh == 0 ? 1 : 0;      // index into pq of the row the partner needs (p1 resp. p2)
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = send ? pq[1][yy][r] : pq[0][yy][r];
+        __syncthreads();
+        float yv[2][16];
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float got = theirs[(16 * yy + r) * 64];
+                yv[yy][r] = xh == 0 ? (pq[0][yy][r] + pq[1][yy][r]) + got      // (p0 + p1) + p2
+                                    : (got - pq[0][yy][r]) - pq[1][yy][r];      // (p1 - p2) - p3
+            }
+        const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
+        const int gx = x0 + j, gz = z0 + xh;
+        const bool ok0 = gx < W && gz < D && (y0 + 2 * ty) < H;
+        const bool ok1 = gx < W && gz < D && (y0 + 2 * ty + 1) < H;
+        if (FUSED && a.stats) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + 2 * ty + xh;
+            stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, a.stats, (int64_t)n * a.Cout,
+                              co0 + 32 * ct, a.Cout, a.nparts, pidx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            if (!(yy == 0 ? ok0 : ok1)) continue;
+            const int gy = y0 + 2 * ty + yy;
+            const int sp1 = (gz * H + gy) * W + gx;
+            const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float val = yv[yy][r];
+                if (!FUSED || a.stats == nullptr) {
+                    if (a.bias) val += a.bias[co];
+                }
+                if (co < a.dst.C1)
+                    a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
+                else
+                    a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct WgradArgs {
     CatView src;      // x (possibly a virtual concatenation)
     const float* dy;  // [N][Cout][D][H][W]
@@ -1057,6 +1346,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a
     };
     auto store_box = [&]() {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #pragma unroll
         for (int p = 0; p < DYP; ++p)
             if (d_act && (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B))
@@ -1169,6 +1459,7 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
     static_assert((COS * CIT == 8 || COS * CIT == 4) && BX % 4 == 0 && POS % 8 == 0 && PB % 2 == 0 && RA % 2 == 0 && DY_CPP >= 1 &&
                       XI_CPP >= 1 && XE_CPP >= 1, "block geometry");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // stage layout: dY [CO_B][4][POS] (+2), then X [CI_B][4][HY][HXP]; halo x index h of a row at column h
@@ -1577,6 +1868,68 @@ __global__ void pack_weights_wz_kernel(const float* __restrict__ w, float* __res
     wz[e] = xi == 0 ? g0 : xi == 1 ? 0.5f * ((g0 + g1) + g2) : xi == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
 }
 
+// Transformed filters of the Winograd-(z,y) kernel: wzy[t = 16 kx + 4 xi_z + xi_y][chunk][kh][Ko][kk] =
+// (G g[:,:,kx] G^T)[xi_z][xi_y] for GEMM input channel 4 chunk + 2 kk + kh (zero beyond Ki) and GEMM output channel
+// 0..Ko-1; mode 0: Ko = Cout, Ki = Cin; mode 1 (backward-data): Ko = Cin, Ki = Cout, taps flipped.
+__device__ __forceinline__ float wino_g(float g0, float g1, float g2, int xi) {
+    return xi == 0 ? g0 : xi == 1 ? 0.5f * ((g0 + g1) + g2) : xi == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
+}
+__global__ void pack_weights_wzy_kernel(const float* __restrict__ w, float* __restrict__ wzy, int Cout, int Cin, int mode) {
+    const int Ko = mode == 0 ? Cout : Cin, Ki = mode == 0 ? Cin : Cout;
+    const int nchunk = (Ki + 3) / 4;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t E = (int64_t)48 * nchunk * 4 * Ko;
+    if (e >= E) return;
+    const int kk = (int)(e % 2);
+    const int ko = (int)((e / 2) % Ko);
+    const int kh = (int)((e / (2 * (int64_t)Ko)) % 2);
+    const int chunk = (int)((e / (4 * (int64_t)Ko)) % nchunk);
+    const int t = (int)(e / (4 * (int64_t)Ko * nchunk));
+    const int ki = 4 * chunk + 2 * kk + kh;
+    if (ki >= Ki) { wzy[e] = 0.f; return; }
+    const int kx = t / 16, xz = (t % 16) / 4, xy = t % 4;
+    const float* g = mode == 0 ? w + ((size_t)ko * Cin + ki) * 27 : w + ((size_t)ki * Cin + ko) * 27;
+    float gz[3];        // G along z for each ky
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float g0, g1, g2;
+        if (mode == 0) { g0 = g[ky * 3 + kx]; g1 = g[9 + ky * 3 + kx]; g2 = g[18 + ky * 3 + kx]; }
+        else { const int f = (2 - ky) * 3 + (2 - kx); g0 = g[18 + f]; g1 = g[9 + f]; g2 = g[f]; }
+        gz[ky] = wino_g(g0, g1, g2, xz);
+    }
+    wzy[e] = wino_g(gz[0], gz[1], gz[2], xy);
+}
+
+static inline size_t wzy_floats(int Ko, int Ki) { return (size_t)48 * ((Ki + 3) / 4) * 4 * Ko; }
+
+// ---------------------------------------------------------------------------------------------
+template <bool FUSED>
+static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wzy_kernel<FUSED>, FwdWzyGeom::LDS_BYTES, lds_once, "conv3d_k3_fwd(wzy)")) return rc;
+    a.co_tiles = a.Cout / 64;
+    const int64_t total = (int64_t)nblk * a.co_tiles;
+    if (total > 0x7fffffffLL) {
+        set_error("conv3d_k3_fwd: grid too large");
+        return DRAM_EINVAL;
+    }
+    hipLaunchKernelGGL((conv3d_k3_fwd_wzy_kernel<FUSED>), dim3((unsigned)total), dim3(512), FwdWzyGeom::LDS_BYTES, st, a);
+    return check_launch("conv3d_k3_fwd(wzy)");
+}
+
+static int launch_fwd_wzy(ConvArgs& a, hipStream_t st) {
+    a.nbx = cdiv(a.W, 32);
+    a.nby = cdiv(a.H, 4);
+    a.nbz = cdiv(a.D, 2);
+    const int64_t nblk = (int64_t)a.N * a.nbx * a.nby * a.nbz;
+    if (nblk > 0x7fffffffLL) {
+        set_error("conv3d_k3_fwd: grid too large");
+        return DRAM_EINVAL;
+    }
+    const bool fused = a.coef1 || a.coef2 || a.stats;
+    return fused ? launch_fwd_wzy_f<true>(a, (unsigned)nblk, st) : launch_fwd_wzy_f<false>(a, (unsigned)nblk, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int BX, int BY, int COT, bool FUSED>
 static int launch_fwd_wz_cot(ConvArgs& a, unsigned nblk, hipStream_t st) {
@@ -1666,14 +2019,32 @@ static bool use_wz(const ConvArgs& a) {
 }
 
 // Which forward kernel / box shape a shape gets (shared by the launch and by dram_conv3d_k3_stats_parts).
+// The Winograd-(z,y) kernel: whole 64-channel output tiles, enough input channels, and a volume that its 32x4x2 boxes
+// cover with little padding (it executes 2/3 of the z-only kernel's MFMAs: worth up to ~1.3x padding, taken at 1.2x).
+static bool use_wzy(const ConvArgs& a) {
+    const bool off = getenv("DRAM_CONV_NO_WZY") != nullptr;     // (read per call: A/B tests toggle it inside one process)
+    if (off || !use_wz(a) || a.Cout % 64 != 0 || a.Cin < 8) return false;
+    const double padded = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2;
+    return padded <= 1.2 * (double)a.W * a.H * a.D;
+}
+
 struct FwdChoice {
     bool wz;
+    bool wzy;
     int box;            // index into the kernel family's box table
     int nbx, nby, nbz;  // boxes per sample
+    int parts_per_box;  // statistics partials a box writes per row
 };
 static FwdChoice fwd_choice(const ConvArgs& a) {
     FwdChoice c;
     c.wz = use_wz(a);
+    c.wzy = use_wzy(a);
+    c.parts_per_box = 4;
+    if (c.wzy) {
+        c.box = 0;
+        c.nbx = cdiv(a.W, 32); c.nby = cdiv(a.H, 4); c.nbz = cdiv(a.D, 2);
+        return c;
+    }
     if (c.wz) {
         // position boxes: the padded plane area, weighted by the lanes a box leaves idle (10x10 uses 100 of 128: the
         // 20^3 and 10^3 levels of the reference's 80^3 chunks fit it exactly)
@@ -1700,8 +2071,12 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
 static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     const FwdChoice c = fwd_choice(a);
     if (a.stats) {
-        DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * 4, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
-                     "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * 4);
+        DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * c.parts_per_box, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
+                     "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * c.parts_per_box);
+    }
+    if (c.wzy) {
+        a.wt += (size_t)63 * a.Cin * a.Cout;      // ... and the (z,y)-transformed ones follow those
+        return launch_fwd_wzy(a, st);
     }
     if (c.wz) {
         a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
@@ -1830,7 +2205,8 @@ using namespace dram;
 
 extern "C" size_t dram_conv3d_k3_packed_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
-    return (size_t)(27 + 36) * Cin * Cout;
+    const size_t a = wzy_floats(Cout, Cin), b = wzy_floats(Cin, Cout);     // forward / backward-data orientation
+    return (size_t)(27 + 36) * Cin * Cout + (a > b ? a : b);
 }
 
 extern "C" int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, int Cin, int mode, void* stream) {
@@ -1842,6 +2218,9 @@ extern "C" int dram_conv3d_k3_pack_weights(const float* w, float* wt, int Cout, 
     const int64_t Ez = (int64_t)36 * Cin * Cout;
     hipLaunchKernelGGL(pack_weights_wz_kernel, dim3((unsigned)cdiv64(Ez, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        wt + E, Cout, Cin, mode);
+    const int64_t Ezy = (int64_t)(mode == 0 ? wzy_floats(Cout, Cin) : wzy_floats(Cin, Cout));
+    hipLaunchKernelGGL(pack_weights_wzy_kernel, dim3((unsigned)cdiv64(Ezy, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wt + E + Ez, Cout, Cin, mode);
     return check_launch("conv3d_k3_pack_weights");
 }
 
@@ -1887,7 +2266,7 @@ extern "C" int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W
     ConvArgs a = {};
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     const FwdChoice c = fwd_choice(a);
-    const int64_t parts = (int64_t)c.nbx * c.nby * c.nbz * 4;
+    const int64_t parts = (int64_t)c.nbx * c.nby * c.nbz * c.parts_per_box;
     return parts > 0x7fffffffLL ? 0 : (int)parts;
 }
 
