@@ -39,7 +39,11 @@ PMC_MICRO = 64        # micro-batch of the rocprofv3 --pmc passes behind profile
 
 
 def wz_factor(kernel_name):
-    """Executed / algorithmic MFMA FLOPs of a conv kernel: 2/3 for the Winograd F(2,3)-along-z kernels."""
+    """Executed / algorithmic MFMA FLOPs of a conv kernel: 2/3 for the Winograd F(2,3)-along-z kernels (36 of 54
+    multiply-adds), 4/9 for the F(2x2,3x3)-over-(z,y) kernels (16 products per channel pair and x tap for 4 outputs
+    instead of 36: 24 of 54)."""
+    if "_wzy_" in kernel_name:
+        return 4.0 / 9.0
     return 2.0 / 3.0 if "_wz_" in kernel_name else 1.0
 
 
@@ -255,7 +259,7 @@ def main():
             d = summ[dom]
             # SURVEY section 8(d) counts the ALGORITHMIC work of a 3x3x3 conv as the direct 27-tap form,
             # 54*Cin*Cout FLOP per voxel.  The *_wz_* kernels run Winograd F(2,3) along z: they EXECUTE 2/3 of those
-            # multiply-adds on the fp32 matrix cores (exact fp32).  The roofline fraction prices what was really
+            # multiply-adds on the fp32 matrix cores (exact fp32); the *_wzy_* kernels F(2x2,3x3) over (z,y): 4/9.  The roofline fraction prices what was really
             # issued against the MFMA peak (always <= 1); the direct-equivalent rate is reported beside it.
             alg = d["flops"] / (d["ms"] * 1e-3) / 1e12
             ex = alg * wz_factor(dom)
@@ -267,9 +271,10 @@ def main():
                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                         "launches": d["launches"], "avg_launch_ms": d["ms"] / d["launches"],
                         "traffic": None, "traffic_bytes_per_launch": None,
-                        "note": "achieved/frac = MFMA FLOPs actually issued (Winograd F(2,3) along z: 36 instead of 54 "
-                                "multiply-adds per channel pair and voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = "
-                                "direct-conv FLOPs of SURVEY 8(d) / time"}
+                        "executed_over_algorithmic": wz_factor(dom),
+                        "note": "achieved/frac = MFMA FLOPs actually issued (Winograd: F(2,3) along z executes 36, "
+                                "F(2x2,3x3) over (z,y) 24 of the direct form's 54 multiply-adds per channel pair and "
+                                "voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = direct-conv FLOPs of SURVEY 8(d) / time"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
             # (collected on micro-batches of 16 x 128^3: only that workload has the same launches)
             if os.path.exists(pmc) and (args.size, args.chunks, args.micro) == (128, 64, PMC_MICRO):
@@ -307,7 +312,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "per_gpu_voxels_per_s": value / world,
             "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 where the
+            # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 resp. 4/9 where the
             # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
             "network_executed_frac_of_fp32_peak": value / world * flops_per_voxel * exec_ratio / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "network_algorithmic_equiv_tflops": value / world * flops_per_voxel / 1e12,

@@ -723,16 +723,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 // one intermediate row pair through LDS and each finishes ONE output plane (so a wave again ends with 32 positions x
 // 2 rows x 32 channels, the shape the statistics epilogue and the stores of the z-only kernel work on).
 //
-// Block = 512 threads = 32 x positions x 2 y pairs x 1 z pair (256 voxels) x 64 output channels:
-// wave = (y pair, 32-channel tile, xi_z half); one block per CU (133 KB of LDS: inputs AND filters double-buffered,
-// one barrier per chunk).  What a second resident block covers in the other kernels is scheduled by hand here: the
-// next chunk's global loads are issued at the top of a chunk, its input transform and LDS stores are sliced into the
-// MFMA loop, and LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest
-// LDS axis) one iteration ahead of their MFMAs.
+// Work item = 32 x positions x 2 y pairs x 1 z pair (256 voxels) x 64 output channels; block = 512 threads:
+// wave = (y pair, 32-channel tile, xi_z half); ONE block per CU (133 KB of LDS: inputs AND filters double-buffered,
+// one barrier per chunk of 4 input channels), PERSISTENT: block b of G walks the items b', b' + G, ...  What a second
+// resident block covers in the other kernels is scheduled by hand here, as one software pipeline over the stream of
+// (item, chunk) pairs that does not drain between items:
+//   * the next chunk's global loads (the next item's first chunk at an item's end) are issued at the top of a chunk,
+//     its input transform and LDS stores are sliced into the MFMA loop; filters go global -> LDS directly;
+//   * LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest LDS axis) one
+//     iteration (4 MFMAs) ahead; the last iteration's MFMAs run AFTER the chunk's barrier, behind the first operand
+//     reads of the next chunk, so the barrier and the LDS latency are covered by queued matrix work;
+//   * an item's epilogue runs inside the first iteration of the next item's first chunk.
 // Staging: wave w owns channel c0 + (w & 3) of the chunk; in waves 0-3 a lane = (y pair, x < 32) transforms one 4x4
 // patch (16 loads, 32 adds, 16 stores); waves 4-7 do the same for the two extra halo columns (4 lanes).
 // Filters: wzy[t = 16 kx + xi][chunk][kh][Cout][kk] (channel = 4 chunk + 2 kk + kh), zero-filled to whole chunks by
-// pack_weights_wzy_kernel, so that a chunk's [48][2][64][2] tile is copied with 16-byte loads and stores.
+// pack_weights_wzy_kernel, so that a chunk's [48][2][64][2] tile is a lane-linear copy.
 // Serves Cout % 64 == 0, Cin >= 8, volumes that 32x4x2 boxes cover well (fwd_choice); everything else: the z-only kernel.
 struct FwdWzyGeom {
     static constexpr int HX = 34;
@@ -741,73 +746,106 @@ struct FwdWzyGeom {
     static constexpr int IN_STAGE = 2 * KH_STRIDE;      // 4352 floats
     static constexpr int WT_STRIDE = 2 * 64 * 2;        // per filter matrix t: [kh][co][kk]
     static constexpr int W_STAGE = 48 * WT_STRIDE;      // 12288 floats
+    static constexpr int STAGE = IN_STAGE + W_STAGE;    // one stage: inputs, then filters
     static constexpr int WPASS = W_STAGE / 4 / 512;     // 16-byte slots per thread and chunk
-    static constexpr size_t LDS_BYTES = (size_t)2 * (IN_STAGE + W_STAGE) * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(float);
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <bool FUSED = false>
-__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a) {
+__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, int total_items) {
     using G = FwdWzyGeom;
     constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
-    constexpr int WTS = G::WT_STRIDE, W_STAGE = G::W_STAGE, WPASS = G::WPASS;
-    static_assert(8 * 32 * 64 * sizeof(float) <= G::LDS_BYTES, "epilogue exchange fits the (dead) stages");
+    constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE, WPASS = G::WPASS;
+    constexpr int SL0 = 8;         // first of the four iterations that carry the staging slices
+    static_assert(8 * 32 * 64 <= STAGE, "the epilogue exchange fits one (idle) stage");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const lw0 = lds + 2 * IN_STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, 64-channel tile), channel tile fastest
-    const int co0 = (b % a.co_tiles) * 64; b /= a.co_tiles;
-    const int bx = b % a.nbx; b /= a.nbx;
-    const int by = b % a.nby; b /= a.nby;
-    const int bz = b % a.nbz;
-    const int n = b / a.nbz;
-    const int x0 = bx * 32, y0 = by * 4, z0 = bz * 2;
+    // this block's items: r, r + G, r + 2G, ... (item = (box, 64-channel tile), channel tile fastest; G blocks).  In one
+    // round the blocks of an XCD (hardware block b runs on XCD b % 8) work on G/8 consecutive items: neighbouring boxes
+    // (shared halos), the tiles that share a box and the same filter chunks meet in that XCD's L2 at about the same time.
+    const int item_step = (int)gridDim.x;
+    const int item_lo = xcd_remap(blockIdx.x, gridDim.x), item_hi = total_items;
+    if (item_lo >= item_hi) return;
     const int D = a.D, H = a.H, W = a.W;
     const int S = D * H * W;
     const int S2 = a.src.D2 * a.src.H2 * a.src.W2;
+    const int Cin = a.Cin;
+    // Scalar registers are scarce in the pipeline below (the compiler keeps every kernel argument it sees used in the
+    // loop live, and spills the excess to VGPR lanes): the once-per-item code reads its arguments afresh from the
+    // kernarg segment through a pointer the optimiser cannot see through.
+    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+    auto kargs = [&]() {
+        KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return kp;
+    };
 
     // ---- staging role: channel c0 + (wave & 3); waves 0-3: lane = (y pair, hx < 32); waves 4-7: lanes 0..3 = (y pair, hx = 32, 33) ----
-    const int s_ci = wave & 3, s_kk = s_ci >> 1, s_kh = s_ci & 1;
+    const int s_ci = wave & 3;
+    const bool st_extra = wave >= 4;
+    const int i_ty = st_extra ? (lane >> 1) & 1 : lane >> 5;
+    const int i_hx = st_extra ? 32 + (lane & 1) : lane & 31;
+    const bool st_ok = !st_extra || lane < 4;
+    const int st_idx = (s_ci & 1) * KHS + (i_ty * HX + i_hx) * 2 + (s_ci >> 1);   // LDS float index of the item's xi = 0 element
+    // per staged item (set_staging_item):
     unsigned off1[4], off2[4];     // in-plane byte offsets of the patch rows in source 1 / 2 (OOB: outside, or no item)
-    int st_idx;                    // LDS float index of this item's xi = 0 element
-    bool st_ok;
-    {
-        const bool extra = wave >= 4;
-        const int i_ty = extra ? (lane >> 1) & 1 : lane >> 5;
-        const int i_hx = extra ? 32 + (lane & 1) : lane & 31;
-        st_ok = !extra || lane < 4;
+    unsigned rowmask[4];           // all ones / zero: row inside the volume
+    const float* sg_base1 = nullptr;   // sample n of source 1 / 2
+    const float* sg_base2 = nullptr;
+    int sg_z0 = 0, sg_row1 = 0, sg_row2 = 0;
+    unsigned wvoff = 0;            // filter slot 0 of the item's channel tile; slot p is 8 filter matrices further
+    const int nchunk = (Cin + 3) >> 2;
+    const unsigned wchunk_bytes = 16u * (unsigned)a.Cout;
+    const unsigned wpass_bytes = 8u * (unsigned)nchunk * wchunk_bytes;
+    const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 48u * 16u * (unsigned)nchunk * (unsigned)a.Cout);
+    const int C1 = a.src.C1;
+    const unsigned plane1 = 4u * (unsigned)(H * W), plane2 = 4u * (unsigned)(a.src.H2 * a.src.W2);
+    const int src_oz = a.src.oz;
+
+    auto decode = [&](KArgs k, int item, int& n, int& x0, int& y0, int& z0, int& co0) {
+        int b = item;
+        const int cot = k->co_tiles, nbx = k->nbx, nby = k->nby, nbz = k->nbz;
+        co0 = (b % cot) * 64; b /= cot;
+        x0 = (b % nbx) * 32; b /= nbx;
+        y0 = (b % nby) * 4; b /= nby;
+        z0 = (b % nbz) * 2;
+        n = b / nbz;
+    };
+    auto set_staging_item = [&](int item) {
+        KArgs k = kargs();
+        int n, x0, y0, z0, co0;
+        decode(k, item, n, x0, y0, z0, co0);
+        sg_z0 = z0;
+        const int kC1 = k->src.C1, kC2 = k->src.C2;
+        sg_base1 = k->src.p1 + (size_t)n * kC1 * S;
+        sg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : sg_base1;
+        sg_row1 = n * kC1;
+        sg_row2 = n * kC2 - kC1;
         const int gx = x0 - 1 + i_hx;
+        const int oy = k->src.oy, ox = k->src.ox, W2 = k->src.W2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gy = y0 - 1 + 2 * i_ty + r;
             const bool ok = st_ok && gx >= 0 && gx < W && gy >= 0 && gy < H;
             off1[r] = ok ? 4u * (unsigned)(gy * W + gx) : OOB;
-            off2[r] = ok ? 4u * (unsigned)((gy + a.src.oy) * a.src.W2 + gx + a.src.ox) : OOB;
+            off2[r] = ok ? 4u * (unsigned)((gy + oy) * W2 + gx + ox) : OOB;
+            rowmask[r] = ok ? 0xffffffffu : 0u;
         }
-        st_idx = s_kh * KHS + (i_ty * HX + i_hx) * 2 + s_kk;
-    }
-    bool zok[4];
-    unsigned zoff1[4], zoff2[4];   // plane byte offsets (wave-uniform: the scalar offset of the loads)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int gz = z0 - 1 + q;
-        zok[q] = gz >= 0 && gz < D;
-        zoff1[q] = zok[q] ? 4u * (unsigned)(gz * H * W) : 0u;
-        zoff2[q] = zok[q] ? 4u * (unsigned)((gz + a.src.oz) * a.src.H2 * a.src.W2) : 0u;
-    }
-    const float* s1 = a.src.p1 + (size_t)n * a.src.C1 * S;
-    const float* s2 = a.src.p2 ? a.src.p2 + (size_t)n * a.src.C2 * S2 : s1;
+        const int t = tid >> 6, r = tid & 63;
+        wvoff = 4u * (unsigned)(((t * nchunk) * 2 + (r >> 5)) * k->Cout * 2 + co0 * 2 + 4 * (r & 31));
+    };
 
     // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
     const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
     const int j = lane & 31, kh = lane >> 5;
     const int bbase = kh * KHS + 8 * xh * XI + (ty * HX + j) * 2;
-    const int abase = 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
+    const int abase = IN_STAGE + 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
 
     f32x16 acc[8];
 #pragma unroll
@@ -815,50 +853,72 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // filters: slot f = p*512 + tid of the chunk's [48][2][64][2] tile <- wzy[t][chunk][kh][Cout][kk], copied by
-    // direct-to-LDS loads (no registers, no ds_write: the tile is lane-linear per wave-instruction)
-    const int nchunk = (a.Cin + 3) >> 2;
-    const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 48u * 16u * (unsigned)nchunk * (unsigned)a.Cout);
-    unsigned wvoff;                 // slot 0; slot p is 8 filter matrices further
-    {
-        const int t = tid >> 6, r = tid & 63;
-        const int wkh = r >> 5, q4 = r & 31;
-        wvoff = 4u * (unsigned)(((t * nchunk) * 2 + wkh) * a.Cout * 2 + co0 * 2 + 4 * q4);
-    }
-    const unsigned wchunk_bytes = 16u * (unsigned)a.Cout;
-    const unsigned wpass_bytes = 8u * (unsigned)nchunk * wchunk_bytes;
-
-    float rin[4][4];               // prefetched raw patch [z plane q][row r] of the next chunk
+    float rin[4][4];               // prefetched raw patch [z plane q][row r] of the chunk being staged
+    f32x2 lc_ab = {1.f, 0.f};      // its channel's {a, b} (normalise on load) ...
+    float lc_lo = 0.f;             // ... and ReLU floor (0 / -inf)
+    bool lc_has = false, sg_allz = true;
     const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);
-    LazyCoef lc;
 
-    auto load_chunk = [&](int c0, float* nw) {
-        const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
-#pragma unroll
-        for (int p = 0; p < WPASS; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nw + 4 * (p * 512 + 64 * wave)), 16, (int)wvoff,
-                                                 (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
+    auto load_chunk = [&](int c0, float* nstage) {
         const int ci = c0 + s_ci;                        // wave-uniform
-        const bool first = ci < a.src.C1;
-        const float* plane = first ? s1 + (size_t)ci * S : s2 + (size_t)(ci - a.src.C1) * S2;
-        const unsigned bytes = ci < a.Cin ? 4u * (unsigned)(first ? S : S2) : 0u;
-        const float* up = uniform_ptr(plane);
+        const bool first = ci < C1;
+        const unsigned sx = (unsigned)(first ? S : S2);
+        const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
+        const unsigned bytes = ci < Cin ? 4u * sx : 0u;
+        const float* up = uniform_ptr(base);
+        const unsigned plane = first ? plane1 : plane2;
+        const int zadd = first ? 0 : src_oz;
+        sg_allz = sg_z0 >= 1 && sg_z0 + 2 < D;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok[q] ? bytes : 0u);   // a plane outside the volume: all zeros
-            const unsigned so = first ? zoff1[q] : zoff2[q];
+            const int gz = sg_z0 - 1 + q;
+            const bool zok = gz >= 0 && gz < D;
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
+            const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
         }
-        if (lazy) lc = lazy_coef(a, n, ci);
+        if (lazy) {     // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar memory path, which
+                        // shares its counter with the LDS operand reads, out of the loop
+            const float* cf = first ? a.coef1 : a.coef2;
+            lc_has = cf != nullptr && ci < Cin;
+            const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
+            const __amdgpu_buffer_rsrc_t csrd = make_rsrc(uniform_ptr(cf), lc_has ? 0x7ffffff0u : 0u);
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
+            lc_ab = __builtin_bit_cast(f32x2, raw);
+            lc_lo = (lc_has && (first ? a.relu1 : a.relu2)) ? 0.f : -INFINITY;
+        }
+        // the filters last: loads return in order, and the patch is wanted first (mid-chunk; the filters at the barrier)
+        const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+                                                     (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
     };
-    // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor
+    // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
+    // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
     auto activate = [&]() {
+        const float ca = lc_has ? lc_ab[0] : 1.f, cb = lc_has ? lc_ab[1] : 0.f;
+        float br[4], lor[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 4; ++r) {
+            br[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[r]);
+            lor[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[r]);
+        }
+        if (sg_allz) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rin[q][r] = (zok[q] && off1[r] != OOB) ? fmaxf(fmaf(lc.a, rin[q][r], lc.b), lc.lo) : 0.f;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rin[q][r] = fmaxf(fmaf(ca, rin[q][r], br[r]), lor[r]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gz = sg_z0 - 1 + q;
+                    rin[q][r] = (gz >= 0 && gz < D) ? fmaxf(fmaf(ca, rin[q][r], br[r]), lor[r]) : 0.f;
+                }
+        }
     };
     auto transform_z = [&]() {                           // B^T d along z (in place)
 #pragma unroll
@@ -876,83 +936,33 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a) {
             o[(4 * q + 3) * XI] = d1 - d3;
         }
     };
-    // One chunk of MFMAs out of stage (lin, lw); with stage_next the staging of the prefetched chunk into (nin, nw) is
-    // sliced between the iterations.  12 iterations of 2 (kx, xi) steps x 2 k-steps = 4 MFMAs, operands one iteration ahead.
-    auto compute = [&](const float* lin, const float* lw, float* nin, bool stage_next) {
-        f32x2 av[2][2], bv[2][2];
-#pragma unroll
-        for (int it = 0; it <= 12; ++it) {
-            if (it < 12) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
-                    av[it & 1][h] = *reinterpret_cast<const f32x2*>(lw + abase + (16 * kx + xi) * WTS);
-                    bv[it & 1][h] = *reinterpret_cast<const f32x2*>(lin + bbase + xi * XI + 2 * kx);
-                }
-            }
-            if (it > 0) {
-                const int i0 = it - 1;
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int xi = (2 * i0 + h) & 7;
-                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
-                    }
-            }
-            if (it >= 5 && it < 11 && stage_next) {      // (block-uniform)
-                if (it == 5 && lazy) activate();
-                if (it == 6) transform_z();
-                if (it >= 7 && it < 11) transform_y_store(nin + st_idx, it - 7);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
 
-    // prologue: chunk 0 straight into stage 0
-    load_chunk(0, lw0);
-    {
-        if (lazy) activate();
-        transform_z();
+    // ---- epilogue of one item: Y = A^T M A; `xch` = an idle LDS stage for the swap between the xi_z halves ----
+    auto epilogue = [&](int item, float* xch) {
+        KArgs k = kargs();
+        int n, x0, y0, z0, co0;
+        decode(k, item, n, x0, y0, z0, co0);
+        // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
+        float pq[2][2][16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int c0 = 0; c0 < a.Cin; c0 += 4) {
-        const bool has_next = (c0 + 4) < a.Cin;
-        const float* lin = lds + cur * IN_STAGE;
-        const float* lw = lw0 + cur * W_STAGE;
-        float* nin = lds + (cur ^ 1) * IN_STAGE;
-        float* nw = lw0 + (cur ^ 1) * W_STAGE;
-        if (has_next) load_chunk(c0 + 4, nw);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(lin, lw, nin, has_next);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- epilogue ----
-    // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
-    float pq[2][2][16];
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+            for (int r = 0; r < 16; ++r) {
+                pq[q][0][r] = (acc[4 * q][r] + acc[4 * q + 1][r]) + acc[4 * q + 2][r];
+                pq[q][1][r] = (acc[4 * q + 1][r] - acc[4 * q + 2][r]) - acc[4 * q + 3][r];
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            pq[q][0][r] = (acc[4 * q][r] + acc[4 * q + 1][r]) + acc[4 * q + 2][r];
-            pq[q][1][r] = (acc[4 * q + 1][r] - acc[4 * q + 2][r]) - acc[4 * q + 3][r];
-        }
-    // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
-    // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1: swap them through LDS (the stages are dead: the loop's
-    // last barrier is behind every read).  Slot layout [wave][register][lane]: conflict-free.
-    {
-        float* mine = lds + (size_t)wave * 32 * 64 + lane;
-        const float* theirs = lds + (size_t)(wave ^ 4) * 32 * 64 + lane;
-        const int send = xh == 0 ? 1 : 0;      // index into pq of the row the partner needs (p1 resp. p2)
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
+        // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1.  Slot layout [wave][register][lane]: conflict-free.
+        float* mine = xch + wave * 32 * 64 + lane;
+        const float* theirs = xch + (wave ^ 4) * 32 * 64 + lane;
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = send ? pq[1][yy][r] : pq[0][yy][r];
+            for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = xh == 0 ? pq[1][yy][r] : pq[0][yy][r];
         __syncthreads();
         float yv[2][16];
 #pragma unroll
@@ -963,36 +973,123 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a) {
                 yv[yy][r] = xh == 0 ? (pq[0][yy][r] + pq[1][yy][r]) + got      // (p0 + p1) + p2
                                     : (got - pq[0][yy][r]) - pq[1][yy][r];      // (p1 - p2) - p3
             }
-        const int dS2 = a.dst.D2 * a.dst.H2 * a.dst.W2;
-        const int gx = x0 + j, gz = z0 + xh;
-        const bool ok0 = gx < W && gz < D && (y0 + 2 * ty) < H;
-        const bool ok1 = gx < W && gz < D && (y0 + 2 * ty + 1) < H;
-        if (FUSED && a.stats) {
+        __syncthreads();           // every wave has read: the stage may be filled again
+        const int gx = x0 + j, gz = z0 + xh, gy = y0 + 2 * ty;
+        const bool ok0 = gx < W && gz < D && gy < H;
+        const bool ok1 = gx < W && gz < D && (gy + 1) < H;
+        const int kCout = k->Cout;
+        float* const kstats = k->stats;
+        if (FUSED && kstats) {
             __builtin_amdgcn_sched_barrier(0);
-            const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + 2 * ty + xh;
-            stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, a.stats, (int64_t)n * a.Cout,
-                              co0 + 32 * ct, a.Cout, a.nparts, pidx);
+            const int cot = k->co_tiles;
+            const int box = (item / cot) % (k->nbx * k->nby * k->nbz);
+            stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, kstats, (int64_t)n * kCout,
+                              co0 + 32 * ct, kCout, k->nparts, box * 4 + 2 * ty + xh);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        // stores: the wave's 32 channels lie in ONE destination tensor (host: dst.C1 % 32 == 0) -> one descriptor over
+        // them, lane offset = (its 4 kh channels, its voxel), the register's channel as a scalar offset
+        const int cw = co0 + 32 * ct;
+        const int dC1 = k->dst.C1, dC2 = k->dst.C2, dH2 = k->dst.H2, dW2 = k->dst.W2;
+        const int dS2 = k->dst.D2 * dH2 * dW2;
+        const bool t1 = cw < dC1;
+        const float* dbase = t1 ? k->dst.p1 + ((size_t)n * dC1 + cw) * S
+                                : k->dst.p2 + ((size_t)n * dC2 + (cw - dC1)) * dS2;
+        const unsigned cstride = 4u * (unsigned)(t1 ? S : dS2);
+        const unsigned rowb = 4u * (unsigned)(t1 ? W : dW2);
+        const unsigned sp = t1 ? (unsigned)((gz * H + gy) * W + gx)
+                               : (unsigned)(((gz + k->dst.oz) * dH2 + gy + k->dst.oy) * dW2 + gx + k->dst.ox);
+        const __amdgpu_buffer_rsrc_t dsrd = make_rsrc(uniform_ptr(dbase), 32u * cstride);
+        const unsigned v0 = 4u * (unsigned)kh * cstride + 4u * sp;
+        const float* kbias = k->bias;
+        if ((!FUSED || kstats == nullptr) && kbias != nullptr) {
+            float bv16[16];
+            const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(kbias, 4u * (unsigned)kCout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv16[r] = buf_load(bsrd, 4u * (unsigned)(cw + 4 * kh), 4u * (unsigned)((r & 3) + 8 * (r >> 2)));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { yv[0][r] += bv16[r]; yv[1][r] += bv16[r]; }
         }
 #pragma unroll
         for (int yy = 0; yy < 2; ++yy) {
-            if (!(yy == 0 ? ok0 : ok1)) continue;
-            const int gy = y0 + 2 * ty + yy;
-            const int sp1 = (gz * H + gy) * W + gx;
-            const int sp2 = ((gz + a.dst.oz) * a.dst.H2 + gy + a.dst.oy) * a.dst.W2 + gx + a.dst.ox;
+            if (yy == 0 ? ok0 : ok1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                float val = yv[yy][r];
-                if (!FUSED || a.stats == nullptr) {
-                    if (a.bias) val += a.bias[co];
-                }
-                if (co < a.dst.C1)
-                    a.dst.p1[((size_t)n * a.dst.C1 + co) * S + sp1] = val;
-                else
-                    a.dst.p2[((size_t)n * a.dst.C2 + (co - a.dst.C1)) * dS2 + sp2] = val;
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[yy][r]), dsrd, (int)(v0 + yy * rowb),
+                                                          (int)((unsigned)((r & 3) + 8 * (r >> 2)) * cstride), 0);
             }
         }
+    };
+
+    // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged,
+    // exactly one chunk ahead.
+    int s_item = item_lo, s_c0 = 0;
+    auto advance_staging = [&]() {
+        s_c0 += 4;
+        if (s_c0 >= Cin) {
+            s_c0 = 0;
+            s_item += item_step;
+            if (s_item < item_hi) set_staging_item(s_item);
+        }
+    };
+    set_staging_item(s_item);
+    load_chunk(0, lds);                         // prologue: the first chunk straight into stage 0
+    if (lazy) activate();
+    transform_z();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
+    advance_staging();
+    __syncthreads();
+
+    int c_item = item_lo, c_c0 = 0, cur = 0;
+    bool pending = false;                       // the previous chunk's last iteration of MFMAs is still to be issued
+    f32x2 av[2][2], bv[2][2];
+    for (;;) {
+        const bool c_valid = c_item < item_hi;
+        const bool has_next = s_item < item_hi;
+        const bool boundary = pending && (c_c0 == 0);     // the previous chunk completed an item
+        const float* stage = lds + cur * STAGE;
+        float* nstage = lds + (cur ^ 1) * STAGE;
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            if (it > 0 || c_valid) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
+                    av[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + abase + (16 * kx + xi) * WTS);
+                    bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + 2 * kx);
+                }
+            }
+            if (it > 0 || pending) {
+                const int i0 = (it + 11) % 12;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int xi = (2 * i0 + h) & 7;
+                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
+                    }
+            }
+            if (it == 0) {
+                // (the MFMAs of the previous chunk's last iteration are queued: they cover the barrier behind us, the
+                //  latency of the operand reads above and the issue of the next chunk's loads below)
+                if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
+                if (!c_valid) return;
+                if (has_next) load_chunk(s_c0, nstage);
+            }
+            if (it >= SL0 && it < SL0 + 4 && has_next) {    // (block-uniform) staging slices: as late as the barrier allows,
+                if (it == SL0 && lazy) activate();          // the loads issued at the chunk's top are most of a chunk old
+                if (it == SL0) transform_z();
+                transform_y_store(nstage + st_idx, it - SL0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pending = true;
+        if (has_next) advance_staging();
+        __syncthreads();
+        cur ^= 1;
+        c_c0 += 4;
+        if (c_c0 >= Cin) { c_c0 = 0; c_item += item_step; }
     }
 }
 
@@ -1903,6 +2000,18 @@ __global__ void pack_weights_wzy_kernel(const float* __restrict__ w, float* __re
 static inline size_t wzy_floats(int Ko, int Ki) { return (size_t)48 * ((Ki + 3) / 4) * 4 * Ko; }
 
 // ---------------------------------------------------------------------------------------------
+static int persistent_blocks() {       // one block per CU of the current device
+    static int cus[DRAM_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DRAM_MAX_DEVICES) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 template <bool FUSED>
 static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
     static LdsAttrOnce lds_once;
@@ -1913,7 +2022,9 @@ static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    hipLaunchKernelGGL((conv3d_k3_fwd_wzy_kernel<FUSED>), dim3((unsigned)total), dim3(512), FwdWzyGeom::LDS_BYTES, st, a);
+    const int64_t cus = persistent_blocks();
+    const unsigned grid = (unsigned)(total < cus ? total : cus);
+    hipLaunchKernelGGL((conv3d_k3_fwd_wzy_kernel<FUSED>), dim3(grid), dim3(512), FwdWzyGeom::LDS_BYTES, st, a, (int)total);
     return check_launch("conv3d_k3_fwd(wzy)");
 }
 
@@ -2024,6 +2135,10 @@ static bool use_wz(const ConvArgs& a) {
 static bool use_wzy(const ConvArgs& a) {
     const bool off = getenv("DRAM_CONV_NO_WZY") != nullptr;     // (read per call: A/B tests toggle it inside one process)
     if (off || !use_wz(a) || a.Cout % 64 != 0 || a.Cin < 8) return false;
+    if (a.dst.C2 > 0 && a.dst.C1 % 32 != 0) return false;                       // a wave's 32 channels: one destination tensor
+    const int64_t dmax = (int64_t)a.D * a.H * a.W > (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2 ? (int64_t)a.D * a.H * a.W
+                                                                                              : (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2;
+    if (dmax * 4 * 36 > 0xffffffffLL) return false;                             // ... behind one 32-bit descriptor
     const double padded = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2;
     return padded <= 1.2 * (double)a.W * a.H * a.D;
 }

@@ -10,6 +10,7 @@ from dram_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--relu2", type=int, default=0)
 ap.add_argument("--shapes", default="4,32,64,128;4,64,64,128;4,192,64,128;8,64,128,64;8,384,128,64;8,128,128,64;16,128,256,32;16,768,256,32;16,256,256,32")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -122,7 +123,7 @@ for spec in args.shapes.split(";"):
     flops = 54.0 * Ci * Co * N * S ** 3
 
     def fwd(cf, stt):
-        return lambda: _lib.call("dram_conv3d_k3_fwd_fused", p(x), Ci, p(cf), 1, None, 0, None, 0, 0, 0, 0, 0, 0, 0, p(wt), None,
+        return lambda: _lib.call("dram_conv3d_k3_fwd_fused", p(x), Ci, p(cf), 1, None, 0, None, args.relu2, 0, 0, 0, 0, 0, 0, p(wt), None,
                                  p(y), p(stt), nparts if stt is not None else 0, N, Co, S, S, S, st)
     out = []
     for mode in ("wzy", "wz"):
@@ -132,6 +133,8 @@ for spec in args.shapes.split(";"):
             os.environ.pop("DRAM_CONV_NO_WZY", None)
         tp = timeit(fwd(None, None), args.iters)
         tb = timeit(fwd(coef, parts), args.iters)
-        out.append(f"{mode}: plain {tp:7.3f} ms ({flops / tp / 1e9:6.1f} TF/s direct-equiv) fused {tb:7.3f} ms ({flops / tb / 1e9:6.1f})")
+        tl = timeit(fwd(coef, None), args.iters)
+        ts = timeit(fwd(None, parts), args.iters)
+        out.append(f"{mode}: plain {tp:7.3f} ms ({flops / tp / 1e9:6.1f} TF/s direct-equiv) fused {tb:7.3f} ms ({flops / tb / 1e9:6.1f}) lazy-only {tl:7.3f} stats-only {ts:7.3f}")
     os.environ.pop("DRAM_CONV_NO_WZY", None)
     print(f"[{N},{Ci}->{Co},{S}^3] " + " | ".join(out), flush=True)
