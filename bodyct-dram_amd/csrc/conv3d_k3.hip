@@ -728,11 +728,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 // one barrier per chunk of 4 input channels), PERSISTENT: block b of G walks the items b', b' + G, ...  What a second
 // resident block covers in the other kernels is scheduled by hand here, as one software pipeline over the stream of
 // (item, chunk) pairs that does not drain between items:
-//   * the next chunk's global loads (the next item's first chunk at an item's end) are issued at the top of a chunk,
-//     its input transform and LDS stores are sliced into the MFMA loop; filters go global -> LDS directly;
+//   * the next chunk's global loads (the next item's first chunk at an item's end), its input transform and LDS stores
+//     ride in small pieces between the MFMAs of a chunk; filters go global -> LDS directly;
 //   * LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest LDS axis) one
-//     iteration (4 MFMAs) ahead; the last iteration's MFMAs run AFTER the chunk's barrier, behind the first operand
-//     reads of the next chunk, so the barrier and the LDS latency are covered by queued matrix work;
+//     iteration (4 MFMAs) ahead; the last iteration's MFMAs straddle the chunk's barrier (two before it, two behind
+//     the first operand reads of the next chunk), so the barrier and the LDS latency are covered by queued matrix work;
 //   * an item's epilogue runs inside the first iteration of the next item's first chunk.
 // Staging: wave w owns channel c0 + (w & 3) of the chunk; in waves 0-3 a lane = (y pair, x < 32) transforms one 4x4
 // patch (16 loads, 32 adds, 16 stores); waves 4-7 do the same for the two extra halo columns (4 lanes).
@@ -759,7 +759,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     using G = FwdWzyGeom;
     constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
     constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE, WPASS = G::WPASS;
-    constexpr int SL0 = 8;         // first of the four iterations that carry the staging slices
+    constexpr int SL0 = 7;         // first of the four iterations that carry the staging slices (as late as the barrier allows:
+                                   // the loads issued in iterations 1-2 are then most of a chunk old)
     static_assert(8 * 32 * 64 <= STAGE, "the epilogue exchange fits one (idle) stage");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -856,48 +857,52 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     float rin[4][4];               // prefetched raw patch [z plane q][row r] of the chunk being staged
     f32x2 lc_ab = {1.f, 0.f};      // its channel's {a, b} (normalise on load) ...
     float lc_lo = 0.f;             // ... and ReLU floor (0 / -inf)
-    bool lc_has = false, sg_allz = true;
+    bool lc_has = false;
     const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);
 
-    auto load_chunk = [&](int c0, float* nstage) {
-        const int ci = c0 + s_ci;                        // wave-uniform
-        const bool first = ci < C1;
-        const unsigned sx = (unsigned)(first ? S : S2);
-        const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
-        const unsigned bytes = ci < Cin ? 4u * sx : 0u;
-        const float* up = uniform_ptr(base);
-        const unsigned plane = first ? plane1 : plane2;
-        const int zadd = first ? 0 : src_oz;
-        sg_allz = sg_z0 >= 1 && sg_z0 + 2 < D;
+    // The next chunk's loads, in pieces that are issued between MFMAs: piece 0/1 = z planes 0,1 / 2,3 of the patch (+ the
+    // channel's {a, b}), piece 2/3 = the two halves of the filter tile (last: loads return in order, and the patch is
+    // wanted first, mid-chunk; the filters at the barrier).
+    auto load_piece = [&](int c0, float* nstage, int piece) {
+        if (piece < 2) {
+            const int ci = c0 + s_ci;                        // wave-uniform
+            const bool first = ci < C1;
+            const unsigned sx = (unsigned)(first ? S : S2);
+            const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
+            const unsigned bytes = ci < Cin ? 4u * sx : 0u;
+            const float* up = uniform_ptr(base);
+            const unsigned plane = first ? plane1 : plane2;
+            const int zadd = first ? 0 : src_oz;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int gz = sg_z0 - 1 + q;
-            const bool zok = gz >= 0 && gz < D;
-            const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
-            const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
+            for (int q = 2 * piece; q < 2 * piece + 2; ++q) {
+                const int gz = sg_z0 - 1 + q;
+                const bool zok = gz >= 0 && gz < D;
+                const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
+                const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
+                for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
+            }
+            if (piece == 1 && lazy) {   // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar
+                                        // memory path, which shares its counter with the LDS operand reads, out of the loop
+                const float* cf = first ? a.coef1 : a.coef2;
+                lc_has = cf != nullptr && ci < Cin;
+                const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
+                const __amdgpu_buffer_rsrc_t csrd = make_rsrc(uniform_ptr(cf), lc_has ? 0x7ffffff0u : 0u);
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
+                lc_ab = __builtin_bit_cast(f32x2, raw);
+                lc_lo = (lc_has && (first ? a.relu1 : a.relu2)) ? 0.f : -INFINITY;
+            }
+        } else {
+            const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+#pragma unroll
+            for (int p = (piece - 2) * (WPASS / 2); p < (piece - 1) * (WPASS / 2); ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+                                                         (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
         }
-        if (lazy) {     // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar memory path, which
-                        // shares its counter with the LDS operand reads, out of the loop
-            const float* cf = first ? a.coef1 : a.coef2;
-            lc_has = cf != nullptr && ci < Cin;
-            const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
-            const __amdgpu_buffer_rsrc_t csrd = make_rsrc(uniform_ptr(cf), lc_has ? 0x7ffffff0u : 0u);
-            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
-            lc_ab = __builtin_bit_cast(f32x2, raw);
-            lc_lo = (lc_has && (first ? a.relu1 : a.relu2)) ? 0.f : -INFINITY;
-        }
-        // the filters last: loads return in order, and the patch is wanted first (mid-chunk; the filters at the barrier)
-        const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
-#pragma unroll
-        for (int p = 0; p < WPASS; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
-                                                     (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
     };
     // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
     // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
-    auto activate = [&]() {
+    auto activate = [&](int half) {                      // z planes 2*half, 2*half + 1
         const float ca = lc_has ? lc_ab[0] : 1.f, cb = lc_has ? lc_ab[1] : 0.f;
         float br[4], lor[4];
 #pragma unroll
@@ -905,14 +910,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             br[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[r]);
             lor[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[r]);
         }
-        if (sg_allz) {
+        const bool allz = sg_z0 >= 1 && sg_z0 + 2 < D;
+        if (allz) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 2 * half; q < 2 * half + 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rin[q][r] = fmaxf(fmaf(ca, rin[q][r], br[r]), lor[r]);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 2 * half; q < 2 * half + 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int gz = sg_z0 - 1 + q;
@@ -1033,8 +1039,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         }
     };
     set_staging_item(s_item);
-    load_chunk(0, lds);                         // prologue: the first chunk straight into stage 0
-    if (lazy) activate();
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) load_piece(0, lds, piece);     // prologue: the first chunk straight into stage 0
+    if (lazy) { activate(0); activate(1); }
     transform_z();
 #pragma unroll
     for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
@@ -1042,8 +1049,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     __syncthreads();
 
     int c_item = item_lo, c_c0 = 0, cur = 0;
-    bool pending = false;                       // the previous chunk's last iteration of MFMAs is still to be issued
+    bool pending = false;                       // the previous chunk's last two MFMAs are still to be issued
     f32x2 av[2][2], bv[2][2];
+    // The work that rides between the MFMAs of iteration `it`, in two pieces (after the 2nd / the 3rd MFMA), so that no
+    // gap between two MFMAs of a wave is much longer than it has to be: the two waves of a SIMD run in step, and whatever
+    // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
+    // they move stale registers into the idle stage.
+    auto ride = [&](int it, int half, bool has_next, float* nstage) {
+        if (it == 1 && has_next) load_piece(s_c0, nstage, half);
+        if (it == 2 && has_next) load_piece(s_c0, nstage, 2 + half);
+        if (it == SL0 && lazy) activate(half);
+        if (it == SL0 + 1 && half == 0) transform_z();
+        const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
+        if (q >= 0 && q < 4) transform_y_store(nstage + st_idx, q);
+    };
     for (;;) {
         const bool c_valid = c_item < item_hi;
         const bool has_next = s_item < item_hi;
@@ -1052,6 +1071,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         float* nstage = lds + (cur ^ 1) * STAGE;
 #pragma unroll
         for (int it = 0; it < 12; ++it) {
+            const int i0 = (it + 11) % 12;                // the MFMAs issued in this iteration belong to iteration i0
+            const bool go = it > 0 || pending;
             if (it > 0 || c_valid) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1060,30 +1081,31 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                     bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + 2 * kx);
                 }
             }
-            if (it > 0 || pending) {
-                const int i0 = (it + 11) % 12;
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int xi = (2 * i0 + h) & 7;
-                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
-                    }
+            for (int m = 0; m < 4; ++m) {                 // k = m / 2, h = m % 2
+                if (go && (it > 0 || m >= 2)) {           // (the last iteration's first two were issued before the barrier)
+                    const int h = m & 1, k = m >> 1, xi = (2 * i0 + h) & 7;
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
+                }
+                if (m == 1 || m == 2) ride(it, m - 1, has_next, nstage);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (it == 0) {
-                // (the MFMAs of the previous chunk's last iteration are queued: they cover the barrier behind us, the
-                //  latency of the operand reads above and the issue of the next chunk's loads below)
+                // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
+                //  of the operand reads above; the next chunk's loads follow in iterations 1 and 2)
                 if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
                 if (!c_valid) return;
-                if (has_next) load_chunk(s_c0, nstage);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (it >= SL0 && it < SL0 + 4 && has_next) {    // (block-uniform) staging slices: as late as the barrier allows,
-                if (it == SL0 && lazy) activate();          // the loads issued at the chunk's top are most of a chunk old
-                if (it == SL0) transform_z();
-                transform_y_store(nstage + st_idx, it - SL0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        // The last iteration's MFMAs straddle the barrier: two before it (matrix work queued while the waves gather), two
+        // after it (behind the next chunk's first operand reads).
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int h = m & 1, k = m >> 1, xi = (2 * 11 + h) & 7;
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][h][k], bv[1][h][k], acc[xi], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         pending = true;
         if (has_next) advance_staging();
         __syncthreads();
@@ -1443,7 +1465,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_wgrad_vec_kernel(WgradArgs a
     };
     auto store_box = [&]() {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #pragma unroll
         for (int p = 0; p < DYP; ++p)
             if (d_act && (DYP * DY_CPP == CO_B || d_c + p * DY_CPP < CO_B))
@@ -1556,7 +1577,6 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
     static_assert((COS * CIT == 8 || COS * CIT == 4) && BX % 4 == 0 && POS % 8 == 0 && PB % 2 == 0 && RA % 2 == 0 && DY_CPP >= 1 &&
                       XI_CPP >= 1 && XE_CPP >= 1, "block geometry");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // stage layout: dY [CO_B][4][POS] (+2), then X [CI_B][4][HY][HXP]; halo x index h of a row at column h
