@@ -859,6 +859,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     float lc_lo = 0.f;             // ... and ReLU floor (0 / -inf)
     bool lc_has = false;
     const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);
+    // The coefficient pointers and ReLU flags of the two sources, parked in VECTOR registers: the scalar file is full in
+    // this kernel, and the compiler would re-load them from the kernarg segment every chunk -- two dependent scalar
+    // loads whose waits (the counter is shared with the LDS operand reads) sit in the middle of the MFMA stream.
+    unsigned cfp[4] = {(unsigned)(unsigned long long)a.coef1, (unsigned)((unsigned long long)a.coef1 >> 32),
+                       (unsigned)(unsigned long long)a.coef2, (unsigned)((unsigned long long)a.coef2 >> 32)};
+    unsigned relu_bits = (a.relu1 ? 1u : 0u) | (a.relu2 ? 2u : 0u);
+    asm volatile("" : "+v"(cfp[0]), "+v"(cfp[1]), "+v"(cfp[2]), "+v"(cfp[3]), "+v"(relu_bits));
 
     // The next chunk's loads, in pieces that are issued between MFMAs: piece 0/1 = z planes 0,1 / 2,3 of the patch (+ the
     // channel's {a, b}), piece 2/3 = the two halves of the filter tile (last: loads return in order, and the patch is
@@ -884,13 +891,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             }
             if (piece == 1 && lazy) {   // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar
                                         // memory path, which shares its counter with the LDS operand reads, out of the loop
-                const float* cf = first ? a.coef1 : a.coef2;
+                const unsigned plo = __builtin_amdgcn_readfirstlane(first ? cfp[0] : cfp[2]);
+                const unsigned phi = __builtin_amdgcn_readfirstlane(first ? cfp[1] : cfp[3]);
+                const float* cf = (const float*)(((unsigned long long)phi << 32) | plo);
+                const unsigned rb = __builtin_amdgcn_readfirstlane(relu_bits);
                 lc_has = cf != nullptr && ci < Cin;
                 const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
-                const __amdgpu_buffer_rsrc_t csrd = make_rsrc(uniform_ptr(cf), lc_has ? 0x7ffffff0u : 0u);
+                const __amdgpu_buffer_rsrc_t csrd = make_rsrc(cf, lc_has ? 0x7ffffff0u : 0u);
                 const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
                 lc_ab = __builtin_bit_cast(f32x2, raw);
-                lc_lo = (lc_has && (first ? a.relu1 : a.relu2)) ? 0.f : -INFINITY;
+                lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
             }
         } else {
             const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;

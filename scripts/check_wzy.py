@@ -52,10 +52,11 @@ def check():
     worst = 0.0
     cases = [  # N, C1, C2, Co, D, H, W, lazy, stats, bias
         (2, 16, 0, 64, 6, 8, 32, False, False, False),
-        (1, 12, 0, 64, 5, 7, 32, True, True, False),       # odd D, H not a multiple of 4, channel tail (12 = 3 chunks)
+        (1, 12, 0, 64, 11, 8, 32, True, True, False),      # odd D, channel tail (12 = 3 chunks)
+        (1, 16, 0, 64, 12, 11, 58, True, True, False),     # ragged y pair, ragged x box
         (2, 10, 0, 128, 4, 12, 64, True, False, False),    # Cin tail inside a chunk
         (1, 8, 8, 64, 8, 8, 32, True, True, False),        # virtual concat, both lazy
-        (1, 24, 0, 64, 3, 9, 70, False, False, True),      # W not a multiple of 32 (padded <= 1.2?), bias
+        (1, 24, 0, 64, 2, 4, 58, False, False, True),      # W not a multiple of 32 (padding 1.10), bias
         (1, 64, 0, 192, 8, 16, 32, False, True, False),
     ]
     for (N, C1, C2, Co, D, H, W, lazy, stats, bias) in cases:

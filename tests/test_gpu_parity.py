@@ -59,6 +59,13 @@ CONV_CASES = [
     (2, 12, 9, 2, 1, 4, True),        # a single plane pair, one row
     (2, 16, 40, 5, 20, 20, False),    # 20^2 planes: 10x10-position forward boxes, 4x8 wgrad boxes, odd D
     (1, 32, 64, 4, 10, 10, False),    # 10^2 planes (deepest level of an 80^3 chunk)
+    # shapes the Winograd-(z,y) kernel serves (Cout % 64 == 0, W covered by 32-wide boxes):
+    (1, 16, 64, 6, 8, 32, True),      # forward only (backward-data has 16 output channels), bias
+    (1, 64, 128, 11, 8, 32, False),   # forward and backward-data; odd D (half-empty last plane pair)
+    (1, 64, 64, 12, 11, 32, False),   # H = 11: ragged last y pair
+    (2, 12, 64, 4, 12, 64, False),    # channel tail inside a chunk (12 = 3 chunks), two boxes along x, two samples
+    (1, 64, 64, 3, 9, 70, True),      # W = 70: partial third box (padding 1.37 > 1.2 -> z-only kernel; the boundary of the rule)
+    (1, 64, 192, 2, 4, 58, False),    # W = 58 (padding 1.10): partial second box through the (z,y) kernel, three channel tiles
 ]
 
 
@@ -112,6 +119,110 @@ def test_conv3d_k3_virtual_concat(shape):
     # and the stand-alone crop_concat_5d kernel
     out = HF.crop_concat(dev(up), dev(skip))
     assert torch.equal(out.cpu(), O.crop_concat_5d(up, skip))
+
+
+def test_conv3d_k3_wzy_kernel_is_selected():
+    """The shapes above that are meant for the Winograd-(z,y) kernel really select it (host rule mirrored in
+    functional.conv_fwd_kernel_name, csrc/conv3d_k3.hip use_wzy)."""
+    from dram_amd import functional as HF
+    assert HF.conv_fwd_kernel_name((11, 8, 32), 128, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
+    assert HF.conv_fwd_kernel_name((11, 8, 32), 64, 128, fused=True) == "conv3d_k3_fwd_wzy_kernel<true>"
+    assert HF.conv_fwd_kernel_name((12, 11, 32), 64, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
+    assert "wz_kernel" in HF.conv_fwd_kernel_name((5, 7, 32), 128, 64)          # too much padding (1.37)
+    assert HF.conv_fwd_kernel_name((2, 4, 58), 192, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
+    assert "wz_kernel" in HF.conv_fwd_kernel_name((3, 9, 70), 64, 64)          # too much padding
+    assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 32), 16, 64)          # 16 output channels
+    assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel<true>"
+
+
+def test_conv3d_k3_wzy_concat_and_split():
+    """Winograd-(z,y) kernel with a virtual concat source (forward) and a destination split over two tensors at a
+    32-channel boundary (backward-data of the same conv)."""
+    from dram_amd import functional as HF
+    up = torch.randn(1, 32, 4, 8, 32, generator=g(15))
+    skip = torch.randn(1, 32, 6, 11, 35, generator=g(16))
+    Ci, Co = 64, 64
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g(17)) / (Ci * 27) ** 0.5
+    gy = torch.randn(1, Co, 4, 8, 32, generator=g(18))
+    ur, sr, wr = up.clone().requires_grad_(True), skip.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = O.conv3d(O.crop_concat_5d(ur, sr), wr, None, 1)
+    yr.backward(gy)
+    ug, sg, wg = dev(up).requires_grad_(True), dev(skip).requires_grad_(True), dev(w).requires_grad_(True)
+    y = HF.conv3d_k3(ug, wg, None, skip=sg)
+    y.backward(dev(gy))
+    check(y, yr, "wzy cat conv fwd")
+    check(ug.grad, ur.grad, "wzy cat conv d(up)")
+    check(sg.grad, sr.grad, "wzy cat conv d(skip)")
+    check(wg.grad, wr.grad, "wzy cat conv wgrad")
+
+
+@pytest.mark.parametrize("case", [
+    # N, C1, C2, Cout, D, H, W, lazy, stats
+    (1, 12, 0, 64, 11, 8, 32, True, True),       # odd D, channel tail
+    (1, 16, 0, 64, 12, 11, 58, True, True),      # ragged y pair and ragged x box
+    (2, 10, 0, 128, 4, 12, 64, True, False),
+    (1, 8, 8, 64, 8, 8, 32, True, True),         # virtual concat, both sources lazy
+    (1, 64, 0, 192, 8, 16, 32, False, True),     # statistics of a plain source, three channel tiles
+    (3, 16, 0, 64, 2, 4, 32, True, True),        # one plane pair, one box per sample: items of three samples per block
+])
+def test_conv3d_k3_wzy_fused(case):
+    """Fused forward (normalise + ReLU on load, statistics epilogue) of the Winograd-(z,y) kernel through the C ABI:
+    against an fp64 reference and against the z-only kernel (DRAM_CONV_NO_WZY is read per call)."""
+    from dram_amd import functional as HF
+    from dram_amd import _lib
+    N, C1, C2, Co, D, H, W, lazy, stats = case
+    Ci = C1 + C2
+    d = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    x = dev(torch.randn(N, C1, D, H, W, generator=g(21)))
+    x2 = dev(torch.randn(N, C2, D + 2, H + 3, W + 1, generator=g(22))) if C2 else None
+    crop = (1, 2, 1) if C2 else (0, 0, 0)
+    w = dev(torch.randn(Co, Ci, 3, 3, 3, generator=g(23)) / (Ci * 27) ** 0.5)
+    coef = dev(torch.rand(N * C1 * 2, generator=g(24)) + 0.5) if lazy else None
+    coef2 = dev(torch.rand(N * C2 * 2, generator=g(25)) - 0.2) if (lazy and C2) else None
+    wt = HF._pack(w, 0)
+
+    def run(wzy):
+        if wzy:
+            os.environ.pop("DRAM_CONV_NO_WZY", None)
+        else:
+            os.environ["DRAM_CONV_NO_WZY"] = "1"
+        try:
+            y = torch.full((N, Co, D, H, W), float("nan"), device=d)
+            nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W) if stats else 0
+            parts = torch.full((N * Co * nparts * 3,), float("nan"), device=d) if stats else None
+            d2 = (0, 0, 0) if x2 is None else tuple(x2.shape[2:])
+            _lib.call("dram_conv3d_k3_fwd_fused", p(x), C1, p(coef), 1, p(x2), C2, p(coef2), 1, d2[0], d2[1], d2[2], crop[0], crop[1],
+                      crop[2], p(wt), None, p(y), p(parts), nparts, N, Co, D, H, W, st)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DRAM_CONV_NO_WZY", None)
+        return y, parts, nparts
+
+    def act(t, cf):
+        if cf is None:
+            return t.double()
+        c = cf.view(t.shape[0], t.shape[1], 2).double()
+        return torch.relu(t.double() * c[:, :, 0, None, None, None] + c[:, :, 1, None, None, None])
+
+    xin = act(x, coef)
+    if C2:
+        xin = torch.cat([xin, act(x2[:, :, crop[0]:crop[0] + D, crop[1]:crop[1] + H, crop[2]:crop[2] + W], coef2)], 1)
+    ref = torch.nn.functional.conv3d(xin.cpu(), w.double().cpu(), None, padding=1)
+    ya, pa, na = run(True)
+    yb, pb, nb = run(False)
+    check(ya, ref, f"wzy fused fwd {case}")
+    check(yb, ref, f"wz fused fwd {case}")
+    if stats:
+        q = pa.view(N * Co, na, 3).double()
+        cnt = q[:, :, 2].sum(1)
+        mean = (q[:, :, 0] * q[:, :, 2]).sum(1) / cnt
+        m2 = (q[:, :, 1] + q[:, :, 2] * (q[:, :, 0] - mean[:, None]) ** 2).sum(1)
+        r = ya.double().view(N * Co, -1)
+        assert bool((cnt == D * H * W).all()), case
+        assert (mean - r.mean(1)).abs().max().item() < 1e-5, case
+        assert ((m2 - ((r - r.mean(1, keepdim=True)) ** 2).sum(1)).abs() / m2).max().item() < 1e-4, case
 
 
 def test_direct_conv_kernels_still_agree():
