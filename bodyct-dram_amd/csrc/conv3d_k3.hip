@@ -754,6 +754,10 @@ struct FwdWzyGeom {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#ifdef DRAM_WZY_STAMPS      // diagnostics build only (scripts/diag_wzy_stamps.py): s_memtime shares of the chunk loop
+__device__ unsigned long long g_wzy_stamps[16];
+#endif
+
 template <bool FUSED = false>
 __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, int total_items) {
     using G = FwdWzyGeom;
@@ -1061,6 +1065,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     int c_item = item_lo, c_c0 = 0, cur = 0;
     bool pending = false;                       // the previous chunk's last two MFMAs are still to be issued
     f32x2 av[2][2], bv[2][2];
+#ifdef DRAM_WZY_STAMPS
+    unsigned long long st_acc[10] = {};
+#endif
     // The work that rides between the MFMAs of iteration `it`, in two pieces (after the 2nd / the 3rd MFMA), so that no
     // gap between two MFMAs of a wave is much longer than it has to be: the two waves of a SIMD run in step, and whatever
     // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
@@ -1079,6 +1086,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         const bool boundary = pending && (c_c0 == 0);     // the previous chunk completed an item
         const float* stage = lds + cur * STAGE;
         float* nstage = lds + (cur ^ 1) * STAGE;
+#ifdef DRAM_WZY_STAMPS
+        unsigned long long tp = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int it = 0; it < 12; ++it) {
             const int i0 = (it + 11) % 12;                // the MFMAs issued in this iteration belong to iteration i0
@@ -1104,9 +1114,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
                 //  of the operand reads above; the next chunk's loads follow in iterations 1 and 2)
                 if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
+#ifdef DRAM_WZY_STAMPS
+                if (!c_valid && lane == 0)
+                    for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[i], st_acc[i]);
+#endif
                 if (!c_valid) return;
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef DRAM_WZY_STAMPS
+            if (it == 0 || it == 2 || it == 6 || it == 11) {
+                const unsigned long long tn = __builtin_readcyclecounter();
+                st_acc[it == 0 ? (boundary ? 6 : 0) : it == 2 ? 1 : it == 6 ? 2 : 3] += tn - tp;
+                if (it == 0) st_acc[boundary ? 8 : 7] += 1;
+                tp = tn;
+            }
+#endif
         }
         // The last iteration's MFMAs straddle the barrier: two before it (matrix work queued while the waves gather), two
         // after it (behind the next chunk's first operand reads).
@@ -1118,7 +1140,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         __builtin_amdgcn_sched_barrier(0);
         pending = true;
         if (has_next) advance_staging();
+#ifdef DRAM_WZY_STAMPS
+        { const unsigned long long tb = __builtin_readcyclecounter(); st_acc[4] += tb - tp; tp = tb; }
+#endif
         __syncthreads();
+#ifdef DRAM_WZY_STAMPS
+        st_acc[5] += __builtin_readcyclecounter() - tp;
+#endif
         cur ^= 1;
         c_c0 += 4;
         if (c_c0 >= Cin) { c_c0 = 0; c_item += item_step; }
@@ -2347,6 +2375,14 @@ static int check_cat(const char* who, const CatView& v, int D, int H, int W) {
 }  // namespace dram
 
 using namespace dram;
+
+#ifdef DRAM_WZY_STAMPS
+extern "C" int dram_debug_wzy_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {};
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wzy_stamps), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wzy_stamps), sizeof(z));
+}
+#endif
 
 extern "C" size_t dram_conv3d_k3_packed_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
