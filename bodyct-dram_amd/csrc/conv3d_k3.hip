@@ -33,6 +33,7 @@
 // The input of forward and the output of backward-data may be a *virtual*
 // channel concatenation of two tensors (crop_concat_5d fused away).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace dram {
@@ -754,11 +755,19 @@ struct FwdWzyGeom {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// v_mov_b32 with a DPP lane pattern (quad_perm 0x00-0xFF, row_ror:n 0x120 + n, row_mirror 0x140), every lane enabled
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
 #ifdef DRAM_WZY_STAMPS      // diagnostics build only (scripts/diag_wzy_stamps.py): s_memtime shares of the chunk loop
 __device__ unsigned long long g_wzy_stamps[16];
 #endif
 
-template <bool FUSED = false>
+// One instantiation serves plain and fused launches (lazy operands / statistics are runtime-uniform options): a separate
+// plain instantiation measured 2-4 % SLOWER than this one run without the options (241 vs 251, 258 vs 269 TFLOP/s
+// direct-equivalent at 64->64 / 192->64, 128^3), so it was dropped.
 __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, int total_items) {
     using G = FwdWzyGeom;
     constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
@@ -791,13 +800,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         return kp;
     };
 
-    // ---- staging role: channel c0 + (wave & 3); waves 0-3: lane = (y pair, hx < 32); waves 4-7: lanes 0..3 = (y pair, hx = 32, 33) ----
+    // ---- staging role: channel c0 + (wave & 3).  Waves 0-3: lane = (y pair, hx < 32), a whole 4x4 patch per lane (16 loads,
+    // transforms in registers, 16 stores).  Waves 4-7 (the SIMD partners of 0-3) take the two extra halo columns hx = 32, 33:
+    // four patches, spread over the wave as ONE element per lane -- lane = 16 * (2 * y pair + column) + 4 * row r + plane q --
+    // with the transforms across lanes (DPP): ~20 instructions per chunk instead of the ~130 of the patch-per-lane form
+    // (which they would spend on 4 active lanes), so that on every SIMD the patch stager runs beside a wave that does
+    // little else than issue MFMAs. ----
     const int s_ci = wave & 3;
     const bool st_extra = wave >= 4;
-    const int i_ty = st_extra ? (lane >> 1) & 1 : lane >> 5;
-    const int i_hx = st_extra ? 32 + (lane & 1) : lane & 31;
-    const bool st_ok = !st_extra || lane < 4;
-    const int st_idx = (s_ci & 1) * KHS + (i_ty * HX + i_hx) * 2 + (s_ci >> 1);   // LDS float index of the item's xi = 0 element
+    const int e_q = lane & 3, e_r = (lane >> 2) & 3;
+    const int i_ty = lane >> 5;
+    const int i_hx = st_extra ? 32 + ((lane >> 4) & 1) : lane & 31;
+    // LDS float index of the lane's xi = 0 element (patch stagers) / of its one element xi = (q, r) (column stagers)
+    const int st_idx = (s_ci & 1) * KHS + (i_ty * HX + i_hx) * 2 + (s_ci >> 1) + (st_extra ? (4 * e_q + e_r) * XI : 0);
+    // B^T along one axis, across the four lanes i = 0..3 of that axis: out_i = sa_i v_i + sb_i v_t(i), t = (2, 2, 1, 1)
+    const float e_saz = e_q == 3 ? -1.f : 1.f, e_sbz = (e_q & 1) ? 1.f : -1.f;
+    const float e_say = e_r == 3 ? -1.f : 1.f, e_sby = (e_r & 1) ? 1.f : -1.f;
+    const bool e_mid = e_r == 1 || e_r == 2;
     // per staged item (set_staging_item):
     unsigned off1[4], off2[4];     // in-plane byte offsets of the patch rows in source 1 / 2 (OOB: outside, or no item)
     unsigned rowmask[4];           // all ones / zero: row inside the volume
@@ -822,335 +841,384 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         z0 = (b % nbz) * 2;
         n = b / nbz;
     };
-    auto set_staging_item = [&](int item) {
-        KArgs k = kargs();
-        int n, x0, y0, z0, co0;
-        decode(k, item, n, x0, y0, z0, co0);
-        sg_z0 = z0;
-        const int kC1 = k->src.C1, kC2 = k->src.C2;
-        sg_base1 = k->src.p1 + (size_t)n * kC1 * S;
-        sg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : sg_base1;
-        sg_row1 = n * kC1;
-        sg_row2 = n * kC2 - kC1;
-        const int gx = x0 - 1 + i_hx;
-        const int oy = k->src.oy, ox = k->src.ox, W2 = k->src.W2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 - 1 + 2 * i_ty + r;
-            const bool ok = st_ok && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            off1[r] = ok ? 4u * (unsigned)(gy * W + gx) : OOB;
-            off2[r] = ok ? 4u * (unsigned)((gy + oy) * W2 + gx + ox) : OOB;
-            rowmask[r] = ok ? 0xffffffffu : 0u;
-        }
-        const int t = tid >> 6, r = tid & 63;
-        wvoff = 4u * (unsigned)(((t * nchunk) * 2 + (r >> 5)) * k->Cout * 2 + co0 * 2 + 4 * (r & 31));
-    };
-
-    // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
-    const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
-    const int j = lane & 31, kh = lane >> 5;
-    const int bbase = kh * KHS + 8 * xh * XI + (ty * HX + j) * 2;
-    const int abase = IN_STAGE + 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    float rin[4][4];               // prefetched raw patch [z plane q][row r] of the chunk being staged
-    f32x2 lc_ab = {1.f, 0.f};      // its channel's {a, b} (normalise on load) ...
-    float lc_lo = 0.f;             // ... and ReLU floor (0 / -inf)
-    bool lc_has = false;
-    const bool lazy = FUSED && (a.coef1 != nullptr || a.coef2 != nullptr);
-    // The coefficient pointers and ReLU flags of the two sources, parked in VECTOR registers: the scalar file is full in
-    // this kernel, and the compiler would re-load them from the kernarg segment every chunk -- two dependent scalar
-    // loads whose waits (the counter is shared with the LDS operand reads) sit in the middle of the MFMA stream.
-    unsigned cfp[4] = {(unsigned)(unsigned long long)a.coef1, (unsigned)((unsigned long long)a.coef1 >> 32),
-                       (unsigned)(unsigned long long)a.coef2, (unsigned)((unsigned long long)a.coef2 >> 32)};
-    unsigned relu_bits = (a.relu1 ? 1u : 0u) | (a.relu2 ? 2u : 0u);
-    asm volatile("" : "+v"(cfp[0]), "+v"(cfp[1]), "+v"(cfp[2]), "+v"(cfp[3]), "+v"(relu_bits));
-
-    // The next chunk's loads, in pieces that are issued between MFMAs: piece 0/1 = z planes 0,1 / 2,3 of the patch (+ the
-    // channel's {a, b}), piece 2/3 = the two halves of the filter tile (last: loads return in order, and the patch is
-    // wanted first, mid-chunk; the filters at the barrier).
-    auto load_piece = [&](int c0, float* nstage, int piece) {
-        if (piece < 2) {
-            const int ci = c0 + s_ci;                        // wave-uniform
-            const bool first = ci < C1;
-            const unsigned sx = (unsigned)(first ? S : S2);
-            const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
-            const unsigned bytes = ci < Cin ? 4u * sx : 0u;
-            const float* up = uniform_ptr(base);
-            const unsigned plane = first ? plane1 : plane2;
-            const int zadd = first ? 0 : src_oz;
-#pragma unroll
-            for (int q = 2 * piece; q < 2 * piece + 2; ++q) {
-                const int gz = sg_z0 - 1 + q;
-                const bool zok = gz >= 0 && gz < D;
-                const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
-                const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
-            }
-            if (piece == 1 && lazy) {   // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar
-                                        // memory path, which shares its counter with the LDS operand reads, out of the loop
-                const unsigned plo = __builtin_amdgcn_readfirstlane(first ? cfp[0] : cfp[2]);
-                const unsigned phi = __builtin_amdgcn_readfirstlane(first ? cfp[1] : cfp[3]);
-                const float* cf = (const float*)(((unsigned long long)phi << 32) | plo);
-                const unsigned rb = __builtin_amdgcn_readfirstlane(relu_bits);
-                lc_has = cf != nullptr && ci < Cin;
-                const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
-                const __amdgpu_buffer_rsrc_t csrd = make_rsrc(cf, lc_has ? 0x7ffffff0u : 0u);
-                const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
-                lc_ab = __builtin_bit_cast(f32x2, raw);
-                lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
-            }
-        } else {
-            const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
-#pragma unroll
-            for (int p = (piece - 2) * (WPASS / 2); p < (piece - 1) * (WPASS / 2); ++p)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
-                                                         (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
-        }
-    };
-    // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
-    // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
-    auto activate = [&](int half) {                      // z planes 2*half, 2*half + 1
-        const float ca = lc_has ? lc_ab[0] : 1.f, cb = lc_has ? lc_ab[1] : 0.f;
-        float br[4], lor[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            br[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[r]);
-            lor[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[r]);
-        }
-        const bool allz = sg_z0 >= 1 && sg_z0 + 2 < D;
-        if (allz) {
-#pragma unroll
-            for (int q = 2 * half; q < 2 * half + 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rin[q][r] = fmaxf(fmaf(ca, rin[q][r], br[r]), lor[r]);
-        } else {
-#pragma unroll
-            for (int q = 2 * half; q < 2 * half + 2; ++q)
-#pragma unroll
+    // The whole pipeline is instantiated twice, for the patch stagers (waves 0-3) and the column stagers (waves 4-7), behind
+    // ONE wave-uniform branch: with the role tested inside the loop the prefetch registers become phi nodes over the two
+    // roles' paths, which hipcc resolves with register copies behind `s_waitcnt vmcnt(0)` right after the loads were issued.
+    // Both instances execute the same barriers (same trip counts).
+    auto run = [&](auto role) {
+        constexpr bool EXTRA = decltype(role)::value;
+        auto set_staging_item = [&](int item) {
+            KArgs k = kargs();
+            int n, x0, y0, z0, co0;
+            decode(k, item, n, x0, y0, z0, co0);
+            sg_z0 = z0;
+            const int kC1 = k->src.C1, kC2 = k->src.C2;
+            sg_base1 = k->src.p1 + (size_t)n * kC1 * S;
+            sg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : sg_base1;
+            sg_row1 = n * kC1;
+            sg_row2 = n * kC2 - kC1;
+            const int gx = x0 - 1 + i_hx;
+            const int oy = k->src.oy, ox = k->src.ox, W2 = k->src.W2;
+            if (EXTRA) {             // one element per lane: its whole offset (plane included) and validity
+                const int gy = y0 - 1 + 2 * i_ty + e_r, gz = z0 - 1 + e_q;
+                const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
+                off1[0] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+                off2[0] = ok ? 4u * (unsigned)(((gz + k->src.oz) * k->src.H2 + gy + oy) * W2 + gx + ox) : OOB;
+                rowmask[0] = ok ? 0xffffffffu : 0u;
+            } else {
+    #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gz = sg_z0 - 1 + q;
-                    rin[q][r] = (gz >= 0 && gz < D) ? fmaxf(fmaf(ca, rin[q][r], br[r]), lor[r]) : 0.f;
+                    const int gy = y0 - 1 + 2 * i_ty + r;
+                    const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                    off1[r] = ok ? 4u * (unsigned)(gy * W + gx) : OOB;
+                    off2[r] = ok ? 4u * (unsigned)((gy + oy) * W2 + gx + ox) : OOB;
+                    rowmask[r] = ok ? 0xffffffffu : 0u;
                 }
-        }
-    };
-    auto transform_z = [&]() {                           // B^T d along z (in place)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d0 = rin[0][r], d1 = rin[1][r], d2 = rin[2][r], d3 = rin[3][r];
-            rin[0][r] = d0 - d2; rin[1][r] = d1 + d2; rin[2][r] = d2 - d1; rin[3][r] = d1 - d3;
-        }
-    };
-    auto transform_y_store = [&](float* o, int q) {      // (.) B along y, row xi_z = q -> LDS
-        if (st_ok) {
+            }
+            const int t = tid >> 6, r = tid & 63;
+            wvoff = 4u * (unsigned)(((t * nchunk) * 2 + (r >> 5)) * k->Cout * 2 + co0 * 2 + 4 * (r & 31));
+        };
+
+        // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
+        const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
+        const int j = lane & 31, kh = lane >> 5;
+        const int bbase = kh * KHS + 8 * xh * XI + (ty * HX + j) * 2;
+        const int abase = IN_STAGE + 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
+        // (measured: reading the two operand pairs of an iteration as four ds_read_b64 -- separate opaque bases, so that hipcc
+        //  cannot merge them into ds_read2(st64)_b64 -- is 2-4 % SLOWER, although the merged form has half the LDS rate)
+
+        f32x16 acc[8];
+    #pragma unroll
+        for (int t = 0; t < 8; ++t)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        float rin[4][4];               // prefetched raw patch [z plane q][row r] of the chunk being staged
+        f32x2 lc_ab = {1.f, 0.f};      // its channel's {a, b} (normalise on load) ...
+        float lc_lo = 0.f;             // ... and ReLU floor (0 / -inf)
+        bool lc_has = false;
+        const bool lazy = a.coef1 != nullptr || a.coef2 != nullptr;
+        // The coefficient pointers and ReLU flags of the two sources, parked in VECTOR registers: the scalar file is full in
+        // this kernel, and the compiler would re-load them from the kernarg segment every chunk -- two dependent scalar
+        // loads whose waits (the counter is shared with the LDS operand reads) sit in the middle of the MFMA stream.
+        unsigned cfp[4] = {(unsigned)(unsigned long long)a.coef1, (unsigned)((unsigned long long)a.coef1 >> 32),
+                           (unsigned)(unsigned long long)a.coef2, (unsigned)((unsigned long long)a.coef2 >> 32)};
+        unsigned relu_bits = (a.relu1 ? 1u : 0u) | (a.relu2 ? 2u : 0u);
+        asm volatile("" : "+v"(cfp[0]), "+v"(cfp[1]), "+v"(cfp[2]), "+v"(cfp[3]), "+v"(relu_bits));
+
+        // The next chunk's loads, in pieces that are issued between MFMAs: piece 0/1 = z planes 0,1 / 2,3 of the patch (+ the
+        // channel's {a, b}), piece 2/3 = the two halves of the filter tile (last: loads return in order, and the patch is
+        // wanted first, mid-chunk; the filters at the barrier).
+        auto load_piece = [&](int c0, float* nstage, int piece) {
+            if (piece < 2) {
+                const int ci = c0 + s_ci;                        // wave-uniform
+                const bool first = ci < C1;
+                const unsigned sx = (unsigned)(first ? S : S2);
+                const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
+                const unsigned bytes = ci < Cin ? 4u * sx : 0u;
+                const float* up = uniform_ptr(base);
+                const unsigned plane = first ? plane1 : plane2;
+                const int zadd = first ? 0 : src_oz;
+                if (EXTRA) {
+                    if (piece == 0) rin[0][0] = buf_load(make_rsrc(up, bytes), first ? off1[0] : off2[0], 0u);
+                } else {
+    #pragma unroll
+                    for (int q = 2 * piece; q < 2 * piece + 2; ++q) {
+                        const int gz = sg_z0 - 1 + q;
+                        const bool zok = gz >= 0 && gz < D;
+                        const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
+                        const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
+                    }
+                }
+                if (piece == 1 && lazy) {   // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar
+                                            // memory path, which shares its counter with the LDS operand reads, out of the loop
+                    const unsigned plo = __builtin_amdgcn_readfirstlane(first ? cfp[0] : cfp[2]);
+                    const unsigned phi = __builtin_amdgcn_readfirstlane(first ? cfp[1] : cfp[3]);
+                    const float* cf = (const float*)(((unsigned long long)phi << 32) | plo);
+                    const unsigned rb = __builtin_amdgcn_readfirstlane(relu_bits);
+                    lc_has = cf != nullptr && ci < Cin;
+                    const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
+                    const __amdgpu_buffer_rsrc_t csrd = make_rsrc(cf, lc_has ? 0x7ffffff0u : 0u);
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
+                    lc_ab = __builtin_bit_cast(f32x2, raw);
+                    lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
+                }
+            } else {
+                const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+    #pragma unroll
+                for (int p = (piece - 2) * (WPASS / 2); p < (piece - 1) * (WPASS / 2); ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+                                                             (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
+            }
+        };
+        // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
+        // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
+        auto activate = [&](int half) {                      // z planes 2*half, 2*half + 1
+            // The loaded {a, b} become visible to the optimiser HERE: left to itself it hoists the selects below to just
+            // behind the load (iteration 2), and with them an `s_waitcnt vmcnt(0)` on every load of the chunk just issued --
+            // a whole memory latency in the MFMA stream (+1700 cycles per chunk, with or without a lazy operand).
+            if (half == 0) asm volatile("" : "+v"(lc_ab), "+v"(lc_lo));
+            const float ca = lc_has ? lc_ab[0] : 1.f, cb = lc_has ? lc_ab[1] : 0.f;
+            if (EXTRA) {             // the lane's one element (an element outside the volume was loaded as 0 and stays 0)
+                if (half == 0) {
+                    const float b1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[0]);
+                    const float l1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[0]);
+                    asm("v_fma_f32 %0, %1, %0, %2\n\tv_max_f32 %0, %0, %3" : "+v"(rin[0][0]) : "v"(ca), "v"(b1), "v"(l1));
+                }
+                return;
+            }
+            float br[4], lor[4];
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                br[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[r]);
+                lor[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[r]);
+            }
+            // exactly two instructions per element (as C++, fmaxf() on the masked floor costs a canonicalising v_max each,
+            // and an if/else over the z validity was flattened into both arms plus moves: ~85 instructions per half)
+    #pragma unroll
+            for (int q = 2 * half; q < 2 * half + 2; ++q)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    asm("v_fma_f32 %0, %1, %0, %2\n\tv_max_f32 %0, %0, %3" : "+v"(rin[q][r]) : "v"(ca), "v"(br[r]), "v"(lor[r]));
+            if (!(sg_z0 >= 1 && sg_z0 + 2 < D)) {            // a plane outside the volume (first / last pair only): zeros
+    #pragma unroll
+                for (int q = 2 * half; q < 2 * half + 2; ++q) {
+                    const int gz = sg_z0 - 1 + q;
+                    if (!(gz >= 0 && gz < D)) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) rin[q][r] = 0.f;
+                    }
+                }
+            }
+        };
+        auto transform_z = [&]() {                           // B^T d along z (in place)
+            if (EXTRA) {             // across the quad's four lanes (planes): partner = quad_perm [2, 2, 1, 1]
+                const float t = dpp_mov<0x5A>(rin[0][0]);
+                rin[0][0] = fmaf(e_sbz, t, e_saz * rin[0][0]);
+                return;
+            }
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d0 = rin[0][r], d1 = rin[1][r], d2 = rin[2][r], d3 = rin[3][r];
+                rin[0][r] = d0 - d2; rin[1][r] = d1 + d2; rin[2][r] = d2 - d1; rin[3][r] = d1 - d3;
+            }
+        };
+        auto transform_y_store = [&](float* o, int q) {      // (.) B along y, row xi_z = q -> LDS
+            if (EXTRA) {             // across the four quads (rows) of a 16-lane DPP row; one store per lane
+                if (q == 0) {
+                    const float v = rin[0][0];
+                    const float t2 = dpp_mov<0x128>(v);                     // row_ror:8: the row two further (0 <-> 2, 1 <-> 3)
+                    const float t1 = dpp_mov<0x1B>(dpp_mov<0x140>(v));      // row_mirror, quads reversed back: rows 1 <-> 2 (0 <-> 3)
+                    const float t = e_mid ? t1 : t2;                        // partner row (2, 2, 1, 1)
+                    o[0] = fmaf(e_sby, t, e_say * v);
+                }
+                return;
+            }
             const float d0 = rin[q][0], d1 = rin[q][1], d2 = rin[q][2], d3 = rin[q][3];
             o[(4 * q + 0) * XI] = d0 - d2;
             o[(4 * q + 1) * XI] = d1 + d2;
             o[(4 * q + 2) * XI] = d2 - d1;
             o[(4 * q + 3) * XI] = d1 - d3;
-        }
-    };
+        };
 
-    // ---- epilogue of one item: Y = A^T M A; `xch` = an idle LDS stage for the swap between the xi_z halves ----
-    auto epilogue = [&](int item, float* xch) {
-        KArgs k = kargs();
-        int n, x0, y0, z0, co0;
-        decode(k, item, n, x0, y0, z0, co0);
-        // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
-        float pq[2][2][16];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pq[q][0][r] = (acc[4 * q][r] + acc[4 * q + 1][r]) + acc[4 * q + 2][r];
-                pq[q][1][r] = (acc[4 * q + 1][r] - acc[4 * q + 2][r]) - acc[4 * q + 3][r];
-            }
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
-        // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1.  Slot layout [wave][register][lane]: conflict-free.
-        float* mine = xch + wave * 32 * 64 + lane;
-        const float* theirs = xch + (wave ^ 4) * 32 * 64 + lane;
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = xh == 0 ? pq[1][yy][r] : pq[0][yy][r];
-        __syncthreads();
-        float yv[2][16];
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float got = theirs[(16 * yy + r) * 64];
-                yv[yy][r] = xh == 0 ? (pq[0][yy][r] + pq[1][yy][r]) + got      // (p0 + p1) + p2
-                                    : (got - pq[0][yy][r]) - pq[1][yy][r];      // (p1 - p2) - p3
-            }
-        __syncthreads();           // every wave has read: the stage may be filled again
-        const int gx = x0 + j, gz = z0 + xh, gy = y0 + 2 * ty;
-        const bool ok0 = gx < W && gz < D && gy < H;
-        const bool ok1 = gx < W && gz < D && (gy + 1) < H;
-        const int kCout = k->Cout;
-        float* const kstats = k->stats;
-        if (FUSED && kstats) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int cot = k->co_tiles;
-            const int box = (item / cot) % (k->nbx * k->nby * k->nbz);
-            stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, kstats, (int64_t)n * kCout,
-                              co0 + 32 * ct, kCout, k->nparts, box * 4 + 2 * ty + xh);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // stores: the wave's 32 channels lie in ONE destination tensor (host: dst.C1 % 32 == 0) -> one descriptor over
-        // them, lane offset = (its 4 kh channels, its voxel), the register's channel as a scalar offset
-        const int cw = co0 + 32 * ct;
-        const int dC1 = k->dst.C1, dC2 = k->dst.C2, dH2 = k->dst.H2, dW2 = k->dst.W2;
-        const int dS2 = k->dst.D2 * dH2 * dW2;
-        const bool t1 = cw < dC1;
-        const float* dbase = t1 ? k->dst.p1 + ((size_t)n * dC1 + cw) * S
-                                : k->dst.p2 + ((size_t)n * dC2 + (cw - dC1)) * dS2;
-        const unsigned cstride = 4u * (unsigned)(t1 ? S : dS2);
-        const unsigned rowb = 4u * (unsigned)(t1 ? W : dW2);
-        const unsigned sp = t1 ? (unsigned)((gz * H + gy) * W + gx)
-                               : (unsigned)(((gz + k->dst.oz) * dH2 + gy + k->dst.oy) * dW2 + gx + k->dst.ox);
-        const __amdgpu_buffer_rsrc_t dsrd = make_rsrc(uniform_ptr(dbase), 32u * cstride);
-        const unsigned v0 = 4u * (unsigned)kh * cstride + 4u * sp;
-        const float* kbias = k->bias;
-        if ((!FUSED || kstats == nullptr) && kbias != nullptr) {
-            float bv16[16];
-            const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(kbias, 4u * (unsigned)kCout);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bv16[r] = buf_load(bsrd, 4u * (unsigned)(cw + 4 * kh), 4u * (unsigned)((r & 3) + 8 * (r >> 2)));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { yv[0][r] += bv16[r]; yv[1][r] += bv16[r]; }
-        }
-#pragma unroll
-        for (int yy = 0; yy < 2; ++yy) {
-            if (yy == 0 ? ok0 : ok1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[yy][r]), dsrd, (int)(v0 + yy * rowb),
-                                                          (int)((unsigned)((r & 3) + 8 * (r >> 2)) * cstride), 0);
-            }
-        }
-    };
-
-    // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged,
-    // exactly one chunk ahead.
-    int s_item = item_lo, s_c0 = 0;
-    auto advance_staging = [&]() {
-        s_c0 += 4;
-        if (s_c0 >= Cin) {
-            s_c0 = 0;
-            s_item += item_step;
-            if (s_item < item_hi) set_staging_item(s_item);
-        }
-    };
-    set_staging_item(s_item);
-#pragma unroll
-    for (int piece = 0; piece < 4; ++piece) load_piece(0, lds, piece);     // prologue: the first chunk straight into stage 0
-    if (lazy) { activate(0); activate(1); }
-    transform_z();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
-    advance_staging();
-    __syncthreads();
-
-    int c_item = item_lo, c_c0 = 0, cur = 0;
-    bool pending = false;                       // the previous chunk's last two MFMAs are still to be issued
-    f32x2 av[2][2], bv[2][2];
-#ifdef DRAM_WZY_STAMPS
-    unsigned long long st_acc[10] = {};
-#endif
-    // The work that rides between the MFMAs of iteration `it`, in two pieces (after the 2nd / the 3rd MFMA), so that no
-    // gap between two MFMAs of a wave is much longer than it has to be: the two waves of a SIMD run in step, and whatever
-    // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
-    // they move stale registers into the idle stage.
-    auto ride = [&](int it, int half, bool has_next, float* nstage) {
-        if (it == 1 && has_next) load_piece(s_c0, nstage, half);
-        if (it == 2 && has_next) load_piece(s_c0, nstage, 2 + half);
-        if (it == SL0 && lazy) activate(half);
-        if (it == SL0 + 1 && half == 0) transform_z();
-        const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
-        if (q >= 0 && q < 4) transform_y_store(nstage + st_idx, q);
-    };
-    for (;;) {
-        const bool c_valid = c_item < item_hi;
-        const bool has_next = s_item < item_hi;
-        const bool boundary = pending && (c_c0 == 0);     // the previous chunk completed an item
-        const float* stage = lds + cur * STAGE;
-        float* nstage = lds + (cur ^ 1) * STAGE;
-#ifdef DRAM_WZY_STAMPS
-        unsigned long long tp = __builtin_readcyclecounter();
-#endif
-#pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int i0 = (it + 11) % 12;                // the MFMAs issued in this iteration belong to iteration i0
-            const bool go = it > 0 || pending;
-            if (it > 0 || c_valid) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
-                    av[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + abase + (16 * kx + xi) * WTS);
-                    bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + 2 * kx);
+        // ---- epilogue of one item: Y = A^T M A; `xch` = an idle LDS stage for the swap between the xi_z halves ----
+        auto epilogue = [&](int item, float* xch) {
+            KArgs k = kargs();
+            int n, x0, y0, z0, co0;
+            decode(k, item, n, x0, y0, z0, co0);
+            // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
+            float pq[2][2][16];
+    #pragma unroll
+            for (int q = 0; q < 2; ++q)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pq[q][0][r] = (acc[4 * q][r] + acc[4 * q + 1][r]) + acc[4 * q + 2][r];
+                    pq[q][1][r] = (acc[4 * q + 1][r] - acc[4 * q + 2][r]) - acc[4 * q + 3][r];
                 }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {                 // k = m / 2, h = m % 2
-                if (go && (it > 0 || m >= 2)) {           // (the last iteration's first two were issued before the barrier)
-                    const int h = m & 1, k = m >> 1, xi = (2 * i0 + h) & 7;
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
+    #pragma unroll
+            for (int t = 0; t < 8; ++t)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
+            // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1.  Slot layout [wave][register][lane]: conflict-free.
+            float* mine = xch + wave * 32 * 64 + lane;
+            const float* theirs = xch + (wave ^ 4) * 32 * 64 + lane;
+    #pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = xh == 0 ? pq[1][yy][r] : pq[0][yy][r];
+            __syncthreads();
+            float yv[2][16];
+    #pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float got = theirs[(16 * yy + r) * 64];
+                    yv[yy][r] = xh == 0 ? (pq[0][yy][r] + pq[1][yy][r]) + got      // (p0 + p1) + p2
+                                        : (got - pq[0][yy][r]) - pq[1][yy][r];      // (p1 - p2) - p3
                 }
-                if (m == 1 || m == 2) ride(it, m - 1, has_next, nstage);
+            __syncthreads();           // every wave has read: the stage may be filled again
+            const int gx = x0 + j, gz = z0 + xh, gy = y0 + 2 * ty;
+            const bool ok0 = gx < W && gz < D && gy < H;
+            const bool ok1 = gx < W && gz < D && (gy + 1) < H;
+            const int kCout = k->Cout;
+            float* const kstats = k->stats;
+            if (kstats) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int cot = k->co_tiles;
+                const int box = (item / cot) % (k->nbx * k->nby * k->nbz);
+                stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, kstats, (int64_t)n * kCout,
+                                  co0 + 32 * ct, kCout, k->nparts, box * 4 + 2 * ty + xh);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (it == 0) {
-                // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
-                //  of the operand reads above; the next chunk's loads follow in iterations 1 and 2)
-                if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
-#ifdef DRAM_WZY_STAMPS
-                if (!c_valid && lane == 0)
-                    for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[i], st_acc[i]);
-#endif
-                if (!c_valid) return;
-                __builtin_amdgcn_sched_barrier(0);
+            // stores: the wave's 32 channels lie in ONE destination tensor (host: dst.C1 % 32 == 0) -> one descriptor over
+            // them, lane offset = (its 4 kh channels, its voxel), the register's channel as a scalar offset
+            const int cw = co0 + 32 * ct;
+            const int dC1 = k->dst.C1, dC2 = k->dst.C2, dH2 = k->dst.H2, dW2 = k->dst.W2;
+            const int dS2 = k->dst.D2 * dH2 * dW2;
+            const bool t1 = cw < dC1;
+            const float* dbase = t1 ? k->dst.p1 + ((size_t)n * dC1 + cw) * S
+                                    : k->dst.p2 + ((size_t)n * dC2 + (cw - dC1)) * dS2;
+            const unsigned cstride = 4u * (unsigned)(t1 ? S : dS2);
+            const unsigned rowb = 4u * (unsigned)(t1 ? W : dW2);
+            const unsigned sp = t1 ? (unsigned)((gz * H + gy) * W + gx)
+                                   : (unsigned)(((gz + k->dst.oz) * dH2 + gy + k->dst.oy) * dW2 + gx + k->dst.ox);
+            const __amdgpu_buffer_rsrc_t dsrd = make_rsrc(uniform_ptr(dbase), 32u * cstride);
+            const unsigned v0 = 4u * (unsigned)kh * cstride + 4u * sp;
+            const float* kbias = k->bias;
+            if (kstats == nullptr && kbias != nullptr) {       // (a conv that feeds a norm has no bias: host-checked)
+                float bv16[16];
+                const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(kbias, 4u * (unsigned)kCout);
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) bv16[r] = buf_load(bsrd, 4u * (unsigned)(cw + 4 * kh), 4u * (unsigned)((r & 3) + 8 * (r >> 2)));
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) { yv[0][r] += bv16[r]; yv[1][r] += bv16[r]; }
             }
-#ifdef DRAM_WZY_STAMPS
-            if (it == 0 || it == 2 || it == 6 || it == 11) {
-                const unsigned long long tn = __builtin_readcyclecounter();
-                st_acc[it == 0 ? (boundary ? 6 : 0) : it == 2 ? 1 : it == 6 ? 2 : 3] += tn - tp;
-                if (it == 0) st_acc[boundary ? 8 : 7] += 1;
-                tp = tn;
+    #pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                if (yy == 0 ? ok0 : ok1) {
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[yy][r]), dsrd, (int)(v0 + yy * rowb),
+                                                              (int)((unsigned)((r & 3) + 8 * (r >> 2)) * cstride), 0);
+                }
             }
-#endif
-        }
-        // The last iteration's MFMAs straddle the barrier: two before it (matrix work queued while the waves gather), two
-        // after it (behind the next chunk's first operand reads).
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int h = m & 1, k = m >> 1, xi = (2 * 11 + h) & 7;
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][h][k], bv[1][h][k], acc[xi], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pending = true;
-        if (has_next) advance_staging();
-#ifdef DRAM_WZY_STAMPS
-        { const unsigned long long tb = __builtin_readcyclecounter(); st_acc[4] += tb - tp; tp = tb; }
-#endif
+        };
+
+        // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged,
+        // exactly one chunk ahead.
+        int s_item = item_lo, s_c0 = 0;
+        auto advance_staging = [&]() {
+            s_c0 += 4;
+            if (s_c0 >= Cin) {
+                s_c0 = 0;
+                s_item += item_step;
+                if (s_item < item_hi) set_staging_item(s_item);
+            }
+        };
+        set_staging_item(s_item);
+    #pragma unroll
+        for (int piece = 0; piece < 4; ++piece) load_piece(0, lds, piece);     // prologue: the first chunk straight into stage 0
+        if (lazy) { activate(0); activate(1); }
+        transform_z();
+    #pragma unroll
+        for (int q = 0; q < 4; ++q) transform_y_store(lds + st_idx, q);
+        advance_staging();
         __syncthreads();
-#ifdef DRAM_WZY_STAMPS
-        st_acc[5] += __builtin_readcyclecounter() - tp;
-#endif
-        cur ^= 1;
-        c_c0 += 4;
-        if (c_c0 >= Cin) { c_c0 = 0; c_item += item_step; }
-    }
+
+        int c_item = item_lo, c_c0 = 0, cur = 0;
+        bool pending = false;                       // the previous chunk's last two MFMAs are still to be issued
+        f32x2 av[2][2], bv[2][2];
+    #ifdef DRAM_WZY_STAMPS
+        unsigned long long st_acc[10] = {};
+    #endif
+        // The work that rides between the MFMAs of iteration `it`, in two pieces (after the 2nd / the 3rd MFMA), so that no
+        // gap between two MFMAs of a wave is much longer than it has to be: the two waves of a SIMD run in step, and whatever
+        // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
+        // they move stale registers into the idle stage.
+        auto ride = [&](int it, int half, bool has_next, float* nstage) {
+            if (it == 1 && has_next) load_piece(s_c0, nstage, half);
+            if (it == 2 && has_next) load_piece(s_c0, nstage, 2 + half);
+            if (it == SL0 && lazy) activate(half);
+            if (it == SL0 + 1 && half == 0) transform_z();
+            const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
+            if (q >= 0 && q < 4) transform_y_store(nstage + st_idx, q);
+        };
+        for (;;) {
+            const bool c_valid = c_item < item_hi;
+            const bool has_next = s_item < item_hi;
+            const bool boundary = pending && (c_c0 == 0);     // the previous chunk completed an item
+            const float* stage = lds + cur * STAGE;
+            float* nstage = lds + (cur ^ 1) * STAGE;
+    #ifdef DRAM_WZY_STAMPS
+            unsigned long long tp = __builtin_readcyclecounter();
+    #endif
+    #pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int i0 = (it + 11) % 12;                // the MFMAs issued in this iteration belong to iteration i0
+                const bool go = it > 0 || pending;
+                if (it > 0 || c_valid) {
+    #pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
+                        av[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + abase + (16 * kx + xi) * WTS);
+                        bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + 2 * kx);
+                    }
+                }
+    #pragma unroll
+                for (int m = 0; m < 4; ++m) {                 // k = m / 2, h = m % 2
+                    if (go && (it > 0 || m >= 2)) {           // (the last iteration's first two were issued before the barrier)
+                        const int h = m & 1, k = m >> 1, xi = (2 * i0 + h) & 7;
+                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
+                    }
+                    if (m == 1 || m == 2) ride(it, m - 1, has_next, nstage);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (it == 0) {
+                    // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
+                    //  of the operand reads above; the next chunk's loads follow in iterations 1 and 2)
+                    if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
+    #ifdef DRAM_WZY_STAMPS
+                    if (!c_valid && lane == 0)
+                        for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[i], st_acc[i]);
+    #endif
+                    if (!c_valid) return;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    #ifdef DRAM_WZY_STAMPS
+                if (it == 0 || it == 2 || it == 6 || it == 11) {
+                    const unsigned long long tn = __builtin_readcyclecounter();
+                    st_acc[it == 0 ? (boundary ? 6 : 0) : it == 2 ? 1 : it == 6 ? 2 : 3] += tn - tp;
+                    if (it == 0) st_acc[boundary ? 8 : 7] += 1;
+                    tp = tn;
+                }
+    #endif
+            }
+            // The last iteration's MFMAs straddle the barrier: two before it (matrix work queued while the waves gather), two
+            // after it (behind the next chunk's first operand reads).
+    #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int h = m & 1, k = m >> 1, xi = (2 * 11 + h) & 7;
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][h][k], bv[1][h][k], acc[xi], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pending = true;
+            if (has_next) advance_staging();
+    #ifdef DRAM_WZY_STAMPS
+            { const unsigned long long tb = __builtin_readcyclecounter(); st_acc[4] += tb - tp; tp = tb; }
+    #endif
+            __syncthreads();
+    #ifdef DRAM_WZY_STAMPS
+            st_acc[5] += __builtin_readcyclecounter() - tp;
+    #endif
+            cur ^= 1;
+            c_c0 += 4;
+            if (c_c0 >= Cin) { c_c0 = 0; c_item += item_step; }
+        }
+    };
+    if (st_extra) run(std::true_type{}); else run(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2070,10 +2138,9 @@ static int persistent_blocks() {       // one block per CU of the current device
     return cus[dev];
 }
 
-template <bool FUSED>
 static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wzy_kernel<FUSED>, FwdWzyGeom::LDS_BYTES, lds_once, "conv3d_k3_fwd(wzy)")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wzy_kernel, FwdWzyGeom::LDS_BYTES, lds_once, "conv3d_k3_fwd(wzy)")) return rc;
     a.co_tiles = a.Cout / 64;
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
@@ -2082,7 +2149,7 @@ static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
     }
     const int64_t cus = persistent_blocks();
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    hipLaunchKernelGGL((conv3d_k3_fwd_wzy_kernel<FUSED>), dim3(grid), dim3(512), FwdWzyGeom::LDS_BYTES, st, a, (int)total);
+    hipLaunchKernelGGL(conv3d_k3_fwd_wzy_kernel, dim3(grid), dim3(512), FwdWzyGeom::LDS_BYTES, st, a, (int)total);
     return check_launch("conv3d_k3_fwd(wzy)");
 }
 
@@ -2095,8 +2162,7 @@ static int launch_fwd_wzy(ConvArgs& a, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    const bool fused = a.coef1 || a.coef2 || a.stats;
-    return fused ? launch_fwd_wzy_f<true>(a, (unsigned)nblk, st) : launch_fwd_wzy_f<false>(a, (unsigned)nblk, st);
+    return launch_fwd_wzy_f(a, (unsigned)nblk, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -71,7 +71,7 @@ def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False):
     if Cin >= 8 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):
         padded = -(-dhw[2] // 32) * 32 * -(-dhw[1] // 4) * 4 * -(-dhw[0] // 2) * 2
         if Cout % 64 == 0 and padded <= 1.2 * dhw[0] * dhw[1] * dhw[2] and not os.environ.get("DRAM_CONV_NO_WZY"):
-            return f"conv3d_k3_fwd_wzy_kernel<{flag}>"          # Winograd over (z, y): use_wzy()
+            return "conv3d_k3_fwd_wzy_kernel"                   # Winograd over (z, y): use_wzy(); one instantiation
         box = min([(32, 4), (16, 8), (8, 16), (10, 10)], key=lambda b: -(-dhw[2] // b[0]) * -(-dhw[1] // b[1]))
         return f"conv3d_k3_fwd_wz_kernel<{box[0]}, {box[1]}, {cot}, {flag}>"
     box = _pick_box(dhw, [(32, 4, 2), (16, 4, 4), (8, 8, 4)])

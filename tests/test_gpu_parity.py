@@ -125,14 +125,14 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     """The shapes above that are meant for the Winograd-(z,y) kernel really select it (host rule mirrored in
     functional.conv_fwd_kernel_name, csrc/conv3d_k3.hip use_wzy)."""
     from dram_amd import functional as HF
-    assert HF.conv_fwd_kernel_name((11, 8, 32), 128, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
-    assert HF.conv_fwd_kernel_name((11, 8, 32), 64, 128, fused=True) == "conv3d_k3_fwd_wzy_kernel<true>"
-    assert HF.conv_fwd_kernel_name((12, 11, 32), 64, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
+    assert HF.conv_fwd_kernel_name((11, 8, 32), 128, 64) == "conv3d_k3_fwd_wzy_kernel"
+    assert HF.conv_fwd_kernel_name((11, 8, 32), 64, 128, fused=True) == "conv3d_k3_fwd_wzy_kernel"
+    assert HF.conv_fwd_kernel_name((12, 11, 32), 64, 64) == "conv3d_k3_fwd_wzy_kernel"
     assert "wz_kernel" in HF.conv_fwd_kernel_name((5, 7, 32), 128, 64)          # too much padding (1.37)
-    assert HF.conv_fwd_kernel_name((2, 4, 58), 192, 64) == "conv3d_k3_fwd_wzy_kernel<false>"
+    assert HF.conv_fwd_kernel_name((2, 4, 58), 192, 64) == "conv3d_k3_fwd_wzy_kernel"
     assert "wz_kernel" in HF.conv_fwd_kernel_name((3, 9, 70), 64, 64)          # too much padding
     assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 32), 16, 64)          # 16 output channels
-    assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel<true>"
+    assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel"
 
 
 def test_conv3d_k3_wzy_concat_and_split():
