@@ -220,6 +220,97 @@ __global__ __launch_bounds__(256) void trilinear_fwd_x4_kernel(const float* __re
     }
 }
 
+// LDS-tiled form of the same kernel for magnifications of 2x and more along z and y (the DC3D decoder's x2 resizes):
+// a block produces a TT_Z x TT_Y x Wo tile of TT_CPT planes from the <= TT_RZ x TT_RY source rows the tile touches,
+// fetched ONCE as aligned 16-byte row segments (activated once per source element when the source is lazy) instead of
+// four unaligned 16-byte loads per 16-byte store through the vector L1 (the x4 kernel: 3.4 TB/s), and with the z/y
+// weights multiplied out and the x blend as a small matrix (fewer vector instructions; the same trilinear form, the
+// products rounded in a different order than in trilinear_fwd_x4_kernel).
+constexpr int TT_Z = 4, TT_Y = 8, TT_RZ = 4, TT_RY = 6, TT_CPT = 4, TT_MAXW = 128;
+__global__ __launch_bounds__(256) void trilinear_fwd_tile_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 Axis az, Axis ay, Axis ax, int planes, int nty,
+                                                                 const float* __restrict__ coef, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float tt_tile[];     // [TT_CPT][TT_RZ * TT_RY][ax.in]
+    const int tid = threadIdx.x;
+    const int Win = ax.in, H = ay.in;
+    const int zo0 = (blockIdx.x / nty) * TT_Z, yo0 = (blockIdx.x % nty) * TT_Y;
+    const int zo1 = min(zo0 + TT_Z, az.out) - 1, yo1 = min(yo0 + TT_Y, ay.out) - 1;
+    int zlo, zhi, ylo, yhi, dmy;
+    float f0, f1;
+    src_index(az, zo0, zlo, dmy, f0, f1);
+    src_index(az, zo1, dmy, zhi, f0, f1);
+    src_index(ay, yo0, ylo, dmy, f0, f1);
+    src_index(ay, yo1, dmy, yhi, f0, f1);
+    const int ny = yhi - ylo + 1, nrow = (zhi - zlo + 1) * ny;          // <= TT_RY, TT_RZ * TT_RY (host: scales <= 0.5)
+    const int p0 = blockIdx.y * TT_CPT;
+    const int np = min(TT_CPT, planes - p0);
+    const int64_t Si = (int64_t)az.in * H * Win, So = (int64_t)az.out * ay.out * ax.out;
+    const int pstride = TT_RZ * TT_RY * Win;
+    const float lo = relu ? 0.f : -INFINITY;
+    {   // stage the source rows: 16-byte segments (Win % 4 == 0, x 16-byte aligned: host)
+        const int W4 = Win >> 2, per_plane = nrow * W4;
+        for (int e = tid; e < np * per_plane; e += 256) {
+            const int u = e / per_plane, r = e - u * per_plane;
+            const int row = r / W4, c4 = r - row * W4;
+            const int gz = zlo + row / ny, gy = ylo + row % ny;
+            float4 v = *reinterpret_cast<const float4*>(x + (p0 + u) * Si + ((int64_t)gz * H + gy) * Win + 4 * c4);
+            if (coef) {   // the source is a RAW conv output: interpolate act(a*x + b) (normalise + ReLU on load)
+                const float ca = coef[2 * (p0 + u)], cb = coef[2 * (p0 + u) + 1];
+                v.x = fmaxf(fmaf(ca, v.x, cb), lo); v.y = fmaxf(fmaf(ca, v.y, cb), lo);
+                v.z = fmaxf(fmaf(ca, v.z, cb), lo); v.w = fmaxf(fmaf(ca, v.w, cb), lo);
+            }
+            *reinterpret_cast<float4*>(tt_tile + u * pstride + row * Win + 4 * c4) = v;
+        }
+    }
+    __syncthreads();
+    const int Wo4 = ax.out >> 2;
+    const int nout = TT_Z * TT_Y * Wo4;
+    const bool fixed_x = (256 % Wo4) == 0;       // then a thread keeps its x group over the tile's rows
+    // x blend as a 4x4 matrix over the four source columns [xs, xs + 3] (row k: c0 at column i0(k) - xs, c1 at i1(k) - xs,
+    // zeros elsewhere): 16 multiply-adds per four outputs instead of 8 plus 24 selects -- this kernel is bound by its
+    // vector instructions, not by memory (a non-finite source value therefore spreads over its group of four outputs)
+    int xs = 0, xq_have = -1;
+    float m[4][4];
+    for (int o = tid; o < nout; o += 256) {
+        const int xq = o % Wo4, rr = o / Wo4;
+        const int yo = yo0 + rr % TT_Y, zo = zo0 + rr / TT_Y;
+        if (zo > zo1 || yo > yo1) continue;
+        if (!fixed_x || xq_have != xq) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int i0, i1;
+                float c0, c1;
+                src_index(ax, 4 * xq + k, i0, i1, c0, c1);
+                if (k == 0) xs = i0 < ax.in - 4 ? i0 : ax.in - 4;     // the four source columns [xs, xs + 3]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[k][j] = (i0 - xs == j ? c0 : 0.f) + (i1 - xs == j ? c1 : 0.f);
+            }
+            xq_have = xq;
+        }
+        int z0, z1, y0, y1;
+        float a0, a1, b0, b1;
+        src_index(az, zo, z0, z1, a0, a1);
+        src_index(ay, yo, y0, y1, b0, b1);
+        const int l00 = ((z0 - zlo) * ny + (y0 - ylo)) * Win + xs, l01 = ((z0 - zlo) * ny + (y1 - ylo)) * Win + xs;
+        const int l10 = ((z1 - zlo) * ny + (y0 - ylo)) * Win + xs, l11 = ((z1 - zlo) * ny + (y1 - ylo)) * Win + xs;
+        float* yp = y + p0 * So + ((int64_t)zo * ay.out + yo) * ax.out + 4 * xq;
+        const float w00 = a0 * b0, w01 = a0 * b1, w10 = a1 * b0, w11 = a1 * b1;
+        for (int u = 0; u < np; ++u) {
+            const float* t0 = tt_tile + u * pstride;
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                t[j] = fmaf(w11, t0[l11 + j], fmaf(w10, t0[l10 + j], fmaf(w01, t0[l01 + j], w00 * t0[l00 + j])));
+            float4 ov;
+            ov.x = fmaf(m[0][3], t[3], fmaf(m[0][2], t[2], fmaf(m[0][1], t[1], m[0][0] * t[0])));
+            ov.y = fmaf(m[1][3], t[3], fmaf(m[1][2], t[2], fmaf(m[1][1], t[1], m[1][0] * t[0])));
+            ov.z = fmaf(m[2][3], t[3], fmaf(m[2][2], t[2], fmaf(m[2][1], t[1], m[2][0] * t[0])));
+            ov.w = fmaf(m[3][3], t[3], fmaf(m[3][2], t[2], fmaf(m[3][1], t[1], m[3][0] * t[0])));
+            *reinterpret_cast<float4*>(yp + u * So) = ov;
+        }
+    }
+}
+
 // Adjoint in gather form.  For input index i the outputs that touch it form the contiguous range
 // [lo, hi] = {o : i0(o) in {i-1, i}}; each contributes l0(o) if i0(o)==i plus l1(o) if i1(o)==i.
 __device__ __forceinline__ void touch_range(const Axis& a, int i, int& lo, int& hi) {
@@ -651,7 +742,15 @@ static bool tri_fwd_x4_ok(const float* y, const Axis& ax) {
 }
 static int tri_fwd_launch(const float* x, float* y, const Axis& az, const Axis& ay, const Axis& ax, int planes, const float* coef,
                           int relu, hipStream_t st) {
-    if (tri_fwd_x4_ok(y, ax)) {
+    const bool tiled = tri_fwd_x4_ok(y, ax) && az.half == 0 && ay.half == 0 && az.scale <= 0.5f && ay.scale <= 0.5f &&
+                       (ax.in % 4) == 0 && ax.in <= TT_MAXW && (((uintptr_t)x) & 15) == 0 && cdiv(planes, TT_CPT) <= 65535 &&
+                       getenv("DRAM_TRI_NO_TILE") == nullptr;
+    if (tiled) {
+        const int ntz = cdiv(az.out, TT_Z), nty = cdiv(ay.out, TT_Y);
+        const size_t lds = (size_t)TT_CPT * TT_RZ * TT_RY * ax.in * sizeof(float);      // <= 48 KB
+        hipLaunchKernelGGL(trilinear_fwd_tile_kernel, dim3(ntz * nty, cdiv(planes, TT_CPT)), dim3(256), lds, st, x, y, az, ay, ax,
+                           planes, nty, coef, relu);
+    } else if (tri_fwd_x4_ok(y, ax)) {
         dim3 grid(cdiv(az.out * ay.out * (ax.out / 4), 256), cdiv(planes, TRI_CPT));
         hipLaunchKernelGGL(trilinear_fwd_x4_kernel, grid, dim3(256), 0, st, x, y, az, ay, ax, planes, coef, relu);
     } else {

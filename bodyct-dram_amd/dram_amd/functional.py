@@ -84,7 +84,8 @@ def conv_wgrad_kernel_name(dhw, Cout, Cin=None, lazy=False):
     tile = '8, 1' if Cout > 64 else '4, 2'
     if dhw[2] % 4 == 0 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):   # csrc/conv3d_k3.hip wgrad_plan
         bx = 16 if dhw[2] % 16 == 0 else (8 if dhw[2] % 8 == 0 else 4)
-        return f"conv3d_k3_wgrad_wz_kernel<{bx}, {32 // bx}, {tile}, {'true' if lazy else 'false'}>"
+        # (the 64 co x 32 ci tile whatever Cout; a concat boundary that is a multiple of 16 only gets '8, 1': label only)
+        return f"conv3d_k3_wgrad_wz_kernel<{bx}, {32 // bx}, 4, 2, {'true' if lazy else 'false'}>"
     box = _pick_box(dhw, [(16, 2, 2), (32, 2, 1), (8, 4, 2)])
     kind = "wgrad_vec" if dhw[2] % box[0] == 0 else "wgrad"       # 16-byte staging needs full boxes along x
     return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {tile}>"

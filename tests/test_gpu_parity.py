@@ -405,7 +405,9 @@ def test_maxpool_with_ties(shape):
                                   ((1, 2, 1, 4, 5), (3, 8, 10), None), ((1, 1, 6, 6, 6), (6, 6, 6), None),
                                   ((1, 2, 8, 7, 9), (4, 5, 3), None), ((1, 2, 3, 4, 2), (14, 9, 11), None),
                                   ((2, 9, 4, 4, 4), None, 2), ((1, 5, 9, 10, 40), None, 2), ((2, 3, 16, 16, 16), None, 2),
-                                  ((1, 2, 6, 7, 33), (12, 15, 60), None)])
+                                  ((1, 2, 6, 7, 33), (12, 15, 60), None),
+                                  # the LDS-tiled forward kernel: ragged tiles in z and y, plane tail, widest rows, 3x along x
+                                  ((1, 3, 8, 12, 64), None, 2), ((1, 1, 3, 4, 128), None, 2), ((1, 6, 5, 11, 8), (10, 23, 24), None)])
 def test_trilinear_align_corners(case):
     from dram_amd import functional as HF
     shape, size, sf = case
