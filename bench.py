@@ -14,11 +14,12 @@ reproduced) on this rank's batch of synthetic lobe chunks: 64 chunks of 1x128^3 
 BASELINE.json's metric names), as ONE batch by default (BatchNorm statistics over all 64 chunks, like the
 reference): un-fused, 64x128^3 of saved activations does not fit 288 GB; the fused engine
 (dram_amd/engine.py) keeps the raw conv outputs only and peaks at 251 GB.  `--micro M` runs gradient-accumulated
-micro-batches of M chunks instead (M = 16: 123 GB, +0.7 % throughput, statistics per 16 chunks).  Inputs are
+micro-batches of M chunks instead (M = 16: 123 GB, about +1 % throughput, statistics per 16 chunks).  Inputs are
 resident in HBM before the timed region.  Weak scaling: the per-GPU batch is fixed.
 
 Rank 0 prints one JSON line: metric/value (whole-job voxels/s), roofline of the dominant kernel
-(3x3x3 conv as Winograd-F(2,3)-along-z implicit GEMMs on fp32 MFMA, timed live with HIP events), cpu_baseline (the oracle's
+(3x3x3 conv forward / backward-data as Winograd F(2x2,3x3)-over-(z,y) implicit GEMMs on fp32 MFMA, timed live with HIP
+events: `frac` prices the MFMA FLOPs the kernel really issues, 4/9 of the direct form's), cpu_baseline (the oracle's
 torch-CPU DC3D timed on this box's host cores).
 """
 import argparse
@@ -168,7 +169,10 @@ def main():
                  f"(or run `python bench.py --gpus {args.gpus}`, which starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DRAM_BENCH_FORCE_DIST=1: create the process group even for one rank (rehearsal of the RCCL code path on a 1-GPU box:
+    # `python -m torch.distributed.run --nproc-per-node 1 ... bench.py`)
+    use_dist = world > 1 or (os.environ.get("DRAM_BENCH_FORCE_DIST") and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -180,6 +184,14 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    if use_dist:
+        # RCCL sets up its channels and staging buffers (its own hipMalloc, outside torch's allocator) at the first
+        # collective of a given size class: do that now, while the device is empty -- the step below fills 251 of 288 GB
+        warm = torch.zeros(16 << 20, dtype=torch.float32, device=dev)          # 64 MB, the size of the gradient buckets
+        dist.all_reduce(warm)
+        dist.barrier()
+        torch.cuda.synchronize()
+        del warm
 
     import models
     from dram_amd import functional as HF
@@ -197,7 +209,7 @@ def main():
     vox_per_rank = args.chunks * args.size ** 3
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -220,7 +232,7 @@ def main():
                 micro //= 2
                 if rank == 0:
                     print(f"bench.py: out of memory, retrying with micro-batch {micro}", file=sys.stderr, flush=True)
-    if world > 1:      # every rank must run the same micro-batch (same number of launches between barriers)
+    if use_dist:       # every rank must run the same micro-batch (same number of launches between barriers)
         mt = torch.tensor([micro], device=dev)
         dist.all_reduce(mt, op=dist.ReduceOp.MIN)
         micro = int(mt.item())
@@ -236,7 +248,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timer, HF.TIMER = HF.TIMER, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -286,7 +298,7 @@ def main():
                         roofline["traffic_write_bytes_per_launch"] = t["write_bytes"]
                 except Exception:
                     pass
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     cpu = None
@@ -319,7 +331,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

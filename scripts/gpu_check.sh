@@ -1,5 +1,6 @@
 #!/bin/bash
-# One GPU-box call: GPU test suite, smoke(), default bench, 2-rank rehearsal of `bench.py --gpus 2` over gloo.
+# One GPU-box call: GPU test suite, smoke(), default bench, 2-rank rehearsal of `bench.py --gpus 2` over gloo, 1-rank
+# rehearsal of the bench's RCCL path.
 #   gpurun --timeout 1200 -- 'bash scripts/gpu_check.sh <tag>'
 # A step that times out / is killed (rc >= 124) ends the call: no further GPU step is started after it.
 TAG=${1:-chk}
@@ -19,4 +20,6 @@ step 900 "$O/tests.log" python -m pytest tests -m gpu -q -x --durations=15
 step 200 "$O/smoke.log" python __graft_entry__.py smoke
 step 400 "$O/bench.json" python bench.py
 step 300 "$O/bench_dp2_gloo.json" python bench.py --gpus 2 --backend gloo --chunks 4 --size 64 --micro 4 --no-cpu-baseline
+# the bench's RCCL code path with the one rank a 1-GPU box allows (process group over backend nccl, warm-up all-reduce, barriers)
+DRAM_BENCH_FORCE_DIST=1 step 300 "$O/bench_rccl1.json" python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29871 bench.py --gpus 1 --chunks 4 --size 64 --micro 4 --no-cpu-baseline
 exit 0

@@ -114,3 +114,47 @@ def test_two_rank_step_equals_one_rank_micro_batched_step(backend):
             assert err <= 1e-4 * step + 1e-9, (backend, r, k, err, step)
         assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k   # replicas stay bit-identical
     assert moved >= 0.9 * len(ref)                                # the step really moved the parameters
+
+
+def _rccl_single_worker(port, out):
+    """One rank over backend "nccl" (= RCCL): the calls of the multi-GPU path -- communicator bound to the device,
+    asynchronous SUM all-reduce of the flat gradient buckets, barrier -- on the one GPU of the test box."""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from dram_amd.train_step import DataParallelTrainer
+    m = _model("ln").cuda().train()
+    tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=LR), bucket_mb=0.05)
+    tr.world = 2                                  # take the all-reduce branch (a sum over the one rank: the identity)
+    reg, seg = tr.step(_shard(0), global_batch=N_PER_RANK)
+    dist.barrier()
+    torch.cuda.synchronize()
+    out["params"] = {k: v.detach().cpu() for k, v in m.named_parameters()}
+    out["buckets"] = len(tr.buckets)
+    out["backend"] = dist.get_backend()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_path_single_rank():
+    """The RCCL leg of DataParallelTrainer on hardware: the step through `dist.all_reduce` over backend nccl must leave
+    exactly the weights of the same step without a process group."""
+    _setup_paths()
+    from dram_amd.train_step import DataParallelTrainer
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_single_worker, args=(29950 + os.getpid() % 40, out))
+    p.start()
+    p.join(240)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL single-rank step hung")
+    assert p.exitcode == 0, p.exitcode
+    res = dict(out)
+    assert res["backend"] == "nccl" and res["buckets"] > 3
+    m = _model("ln").cuda().train()
+    tr = DataParallelTrainer(m, torch.optim.SGD(m.parameters(), lr=LR))
+    tr.step(_shard(0))
+    for k, v in m.named_parameters():
+        assert torch.equal(v.detach().cpu(), res["params"][k]), k
