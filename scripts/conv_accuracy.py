@@ -1,5 +1,7 @@
-"""Rounding error of the 3x3x3 conv kernels against an fp64 CPU convolution, Winograd (default) vs direct
-(DRAM_CONV_DIRECT=1, read once per process -> two child processes), and of torch's own fp32 CPU convolution on the same
+"""Rounding error of the 3x3x3 conv kernels against an fp64 CPU convolution: the default kernels (Winograd F(2x2,3x3)
+over (z,y) for forward / backward-data where it applies -- the shapes with 32-wide rows below -- and F(2,3) along z
+otherwise and for backward-weights), the z-only kernels everywhere (DRAM_CONV_NO_WZY=1), the direct kernels
+(DRAM_CONV_DIRECT=1, read once per process -> child processes), and torch's own fp32 CPU convolution on the same
 data as the yardstick.  Errors are max |got - ref64| / max |ref64| and relative L2.
     python scripts/conv_accuracy.py"""
 import os
@@ -16,7 +18,7 @@ def child():
     from dram_amd import functional as HF
     g = torch.Generator().manual_seed(5)
     rows = []
-    for (N, Ci, Co, S) in [(2, 64, 64, 24), (1, 192, 64, 20), (1, 256, 256, 12)]:
+    for (N, Ci, Co, S) in [(2, 64, 64, 24), (1, 192, 64, 20), (1, 256, 256, 12), (1, 64, 64, 32), (1, 192, 64, 32), (1, 256, 256, 32)]:
         x = torch.rand(N, Ci, S, S, S, generator=g)                      # post-ReLU-like, non-negative inputs
         w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * (2.0 / (Ci * 27)) ** 0.5
         gy = torch.randn(N, Co, S, S, S, generator=g)
@@ -35,7 +37,8 @@ def child():
             return ((a - ref).abs().max() / ref.abs().max()).item(), ((a - ref).norm() / ref.norm()).item()
         for name, hip, cpu32, ref in (("fwd", yg, y32, y64), ("dgrad", xg.grad, x32.grad, x64.grad), ("wgrad", wg.grad, w32.grad, w64.grad)):
             (m, l), (m32, l32) = err(hip, ref), err(cpu32, ref)
-            rows.append(f"[{N},{Ci}->{Co},{S}^3] {name:5s}  HIP max {m:.2e} L2 {l:.2e}   torch-CPU-fp32 max {m32:.2e} L2 {l32:.2e}")
+            kern = HF.conv_fwd_kernel_name((S, S, S), Co, Ci).split("_kernel")[0][len("conv3d_k3_"):] if name != "wgrad" else "wgrad"
+            rows.append(f"[{N},{Ci}->{Co},{S}^3] {name:5s} ({kern:7s})  HIP max {m:.2e} L2 {l:.2e}   torch-CPU-fp32 max {m32:.2e} L2 {l32:.2e}")
     print("\n".join(rows))
 
 
@@ -43,6 +46,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for label, env in (("Winograd F(2,3)-z kernels (default)", {}), ("direct kernels (DRAM_CONV_DIRECT=1)", {"DRAM_CONV_DIRECT": "1"})):
+        for label, env in (("default kernels: Winograd (z,y) for fwd / dgrad where it applies, z-only otherwise", {}),
+                           ("Winograd F(2,3)-z kernels everywhere (DRAM_CONV_NO_WZY=1)", {"DRAM_CONV_NO_WZY": "1"}),
+                           ("direct kernels (DRAM_CONV_DIRECT=1)", {"DRAM_CONV_DIRECT": "1"})):
             print("==", label, flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), check=True)
