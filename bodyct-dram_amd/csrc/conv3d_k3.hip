@@ -1673,6 +1673,10 @@ struct WgradWzGeom {
     static constexpr size_t LDS_BYTES = (DOUBLE ? 2 : 1) * (size_t)STAGE * sizeof(float);
 };
 
+#ifdef DRAM_WZY_STAMPS      // diagnostics build only (scripts/diag_wgrad_wz_stamps.py)
+__device__ unsigned long long g_wgrad_stamps[8];
+#endif
+
 template <int BX, int BY, int COS, int CIT, bool LAZY = false>
 __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(WgradArgs a) {
     using G = WgradWzGeom<BX, BY, COS, CIT>;
@@ -1912,17 +1916,38 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
     }
     __syncthreads();
     int cur = 0;
+#ifdef DRAM_WZY_STAMPS
+    unsigned long long st_acc[5] = {};
+#define WG_STAMP(i_) { const unsigned long long tn_ = __builtin_readcyclecounter(); st_acc[i_] += tn_ - tp_; tp_ = tn_; }
+#else
+#define WG_STAMP(i_)
+#endif
     for (int box = sp; box < a.nboxes; box += a.split) {
         const bool has_next = (box + a.split) < a.nboxes;
+#ifdef DRAM_WZY_STAMPS
+        unsigned long long tp_ = __builtin_readcyclecounter();
+        st_acc[4] += 1;
+#endif
         if (has_next) load_box(box + a.split);
         __builtin_amdgcn_sched_barrier(0);
+        WG_STAMP(0)
         if (DOUBLE) {
             // a wave writes the next box into the idle stage as soon as ITS MFMAs are done -- while slower waves still
-            // compute -- and a box costs one barrier
+            // compute -- and a box costs one barrier.  What the stamps (-DDRAM_WZY_STAMPS, scripts/diag_wgrad_wz_stamps.py)
+            // show: every wave issues its 288 MFMAs in 9,400 cycles -- the pipe's full rate -- so the two waves of a SIMD
+            // run their MFMA loops one after the other (the older first; the younger makes no progress meanwhile, not even
+            // through its load phase), and a box takes 21,700 cycles = both loops (18,700) + the first wave's load phase +
+            // the second wave's store phase + the barrier.  Letting the partners take turns on purpose (waves 0-3 compute
+            // first and fetch / store afterwards, waves 4-7 fetch / store first) made a box 25,000 cycles: the younger wave's
+            // fetch only starts when the older one's loop is over, and its latency is then exposed.
             compute(lds + cur * STAGE);
             __builtin_amdgcn_sched_barrier(0);
+            WG_STAMP(1)
             if (has_next) store_box(lds + (cur ^ 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+            WG_STAMP(2)
             __syncthreads();
+            WG_STAMP(3)
             cur ^= 1;
         } else {
             compute(lds);
@@ -1935,6 +1960,11 @@ __global__ __launch_bounds__(64 * COS * CIT, 2) void conv3d_k3_wgrad_wz_kernel(W
         }
     }
 
+#ifdef DRAM_WZY_STAMPS
+    if (lane == 0)
+        for (int q = 0; q < 5; ++q) atomicAdd(&g_wgrad_stamps[q], st_acc[q]);
+#endif
+#undef WG_STAMP
     // G^T p per accumulator element -> the three z taps of each (ky,kx) column
     const int ci = ci0 + wci * 16 + i;
     if (ci < a.Cin) {
@@ -2457,6 +2487,11 @@ extern "C" int dram_debug_wzy_stamps(unsigned long long* out, int reset) {
     unsigned long long z[16] = {};
     if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wzy_stamps), z, sizeof(z));
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wzy_stamps), sizeof(z));
+}
+extern "C" int dram_debug_wgrad_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[8] = {};
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamps), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgrad_stamps), sizeof(z));
 }
 #endif
 

@@ -1,0 +1,33 @@
+"""Diagnostic (not part of the product): s_memtime shares of the Winograd-z backward-weights kernel's box loop (two-stage
+variant), per wave and box: load phase (address arithmetic + issue of the next box's loads), MFMA loop, store phase, barrier.
+Build first (see scripts/diag_wzy_stamps.py): the same -DDRAM_WZY_STAMPS library."""
+import ctypes, os
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "libdram_hip_stamp.so"))
+P, I, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+lib.dram_conv3d_k3_wgrad_fused.argtypes = [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, Z, I, I, I, I, I, P]
+lib.dram_conv3d_k3_wgrad_ws_bytes.restype = Z
+lib.dram_conv3d_k3_wgrad_ws_bytes.argtypes = [I, I, I, I, I, I]
+for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
+    x = torch.rand(N, Ci, S, S, S, device="cuda") - 0.5
+    dy = torch.rand(N, Co, S, S, S, device="cuda") - 0.5
+    dw = torch.empty(Co, Ci, 3, 3, 3, device="cuda")
+    coef = torch.rand(N * Ci * 2, device="cuda") + 0.5
+    nb = lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, S, S, S)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for tag, cf in (("plain", None), ("lazy", coef)):
+        for rep in range(2):
+            lib.dram_debug_wgrad_stamps(None, 1)
+            rc = lib.dram_conv3d_k3_wgrad_fused(x.data_ptr(), Ci, None if cf is None else cf.data_ptr(), 1, None, 0, None, 0, 0, 0, 0, 0, 0, 0,
+                                                dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Co, S, S, S, st)
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+        out = (ctypes.c_ulonglong * 8)()
+        lib.dram_debug_wgrad_stamps(out, 0)
+        nbox = max(out[4], 1)
+        names = ["load phase", "MFMA loop", "store phase", "barrier"]
+        per = [out[q] / nbox for q in range(4)]
+        print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and box {sum(per):.0f} (288 MFMAs x 2 waves = 18432 of matrix pipe): " +
+              ", ".join(f"{names[q]} {per[q]:.0f}" for q in range(4)), flush=True)
