@@ -729,8 +729,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 // one barrier per chunk of 4 input channels), PERSISTENT: block b of G walks the items b', b' + G, ...  What a second
 // resident block covers in the other kernels is scheduled by hand here, as one software pipeline over the stream of
 // (item, chunk) pairs that does not drain between items:
-//   * the next chunk's global loads (the next item's first chunk at an item's end), its input transform and LDS stores
-//     ride in small pieces between the MFMAs of a chunk; filters go global -> LDS directly;
+//   * the next chunk's global loads (the next item's first chunk at an item's end; issued right behind the barrier), its
+//     input transform and LDS stores ride in small pieces between the MFMAs of a chunk; filters go global -> LDS directly;
 //   * LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest LDS axis) one
 //     iteration (4 MFMAs) ahead; the last iteration's MFMAs straddle the chunk's barrier (two before it, two behind
 //     the first operand reads of the next chunk), so the barrier and the LDS latency are covered by queued matrix work;
@@ -772,8 +772,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     using G = FwdWzyGeom;
     constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
     constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE, WPASS = G::WPASS;
-    constexpr int SL0 = 7;         // first of the four iterations that carry the staging slices (as late as the barrier allows:
-                                   // the loads issued in iterations 1-2 are then most of a chunk old)
+    constexpr int SL0 = 7;         // first of the four iterations that carry the staging slices (8 measured the same)
+    // Iterations in which the next chunk's loads are issued: the input patch right behind the barrier (it is wanted first, at
+    // SL0), the filter tile three iterations later (wanted at the chunk's end; never in iteration 0, where an item's epilogue
+    // uses the idle stage as its exchange buffer).  Measured (plain / fused launches, against patch 1 + filters 2): patch 0 +
+    // filters 2: -5 % / -1 %; patch 0 + filters 3 or 4: -6.4 % / -2...0 %; patch 0 + filters 1: +0 % / +2 %.
+    constexpr int LD_IN = 0, LD_W = 3;
     static_assert(8 * 32 * 64 <= STAGE, "the epilogue exchange fits one (idle) stage");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1139,8 +1143,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
         // they move stale registers into the idle stage.
         auto ride = [&](int it, int half, bool has_next, float* nstage) {
-            if (it == 1 && has_next) load_piece(s_c0, nstage, half);
-            if (it == 2 && has_next) load_piece(s_c0, nstage, 2 + half);
+            if (it == LD_IN && has_next) load_piece(s_c0, nstage, half);
+            if (it == LD_W && has_next) load_piece(s_c0, nstage, 2 + half);
             if (it == SL0 && lazy) activate(half);
             if (it == SL0 + 1 && half == 0) transform_z();
             const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 }
                 if (it == 0) {
                     // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
-                    //  of the operand reads above; the next chunk's loads follow in iterations 1 and 2)
+                    //  of the operand reads above; the next chunk's filter loads follow in iteration LD_W)
                     if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
     #ifdef DRAM_WZY_STAMPS
                     if (!c_valid && lane == 0)

@@ -14,7 +14,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 import torch  # noqa: F401  (import order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdram_hip.so")
+# (DRAM_HIP_LIB: another build of the same library -- diagnostics / A-B experiments only)
+LIB_PATH = os.environ.get("DRAM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libdram_hip.so")
 
 P, I, L, F, Z = c_void_p, c_int, c_int64, c_float, c_size_t
 
