@@ -10,7 +10,10 @@
 //   out[b,c,i] = sum_e a[b,e,i] * v[b,c,i+o_e]                                                   (aggregate)
 //
 // with act = identity | ReLU, n_i = identity | L2 normalisation over the node's edges, s = 1 |
-// 1/sqrt(#edges of the node) | 1/0.01 -- the dot-product family of merge_func.  theta, phi, v and the
+// 1/sqrt(#edges of the node) | 1/0.01 -- the dot-product family of merge_func.  The geo variants of merge_func
+// (scaled_dot_product_geo(_relu), att_is_all: an appearance term plus a positional-encoding term) are the same
+// kernels on concatenated / summed feature planes, with the ReLU confined to the first F_relu feature planes:
+// logit = act(sum_{f < F_relu} theta_f phi_f) + sum_{f >= F_relu} theta_f phi_f.  theta, phi, v and the
 // result are NCDHW planes; the attention weights are kept as E planes [B,E,S] (saved for the backward
 // and re-used by every non_local_iter).  HBM-bound stencil work, one thread per node along x;
 // every reduction is a gather (no atomics), so results are deterministic.
@@ -48,7 +51,7 @@ __device__ __forceinline__ float pcm_scale(int scale_mode, float deg) {
 // ---------------------------------------------------------------- attention weights
 __global__ __launch_bounds__(256) void pcm_attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
                                                            float* __restrict__ attn, PcmOffsets o, PcmGrid g, int F,
-                                                           int flags, int scale_mode) {
+                                                           int F_relu, int flags, int scale_mode) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.S) return;
     const int b = blockIdx.y;
@@ -62,8 +65,11 @@ __global__ __launch_bounds__(256) void pcm_attn_fwd_kernel(const float* __restri
         int64_t j;
         float u = 0.f;
         if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
-            for (int f = 0; f < F; ++f) u = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], u);
+            for (int f = 0; f < F_relu; ++f) u = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], u);
             if (flags & PCM_RELU) u = fmaxf(u, 0.f);
+            float u2 = 0.f;                                     // (the feature planes outside the activation)
+            for (int f = F_relu; f < F; ++f) u2 = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], u2);
+            u += u2;
             deg += 1.f;
             umax = fmaxf(umax, u);
             ss = fmaf(u, u, ss);
@@ -93,8 +99,9 @@ __global__ __launch_bounds__(256) void pcm_attn_fwd_kernel(const float* __restri
 // dlogit (gradient w.r.t. the raw dot products) from dattn; dtheta from it.  ds has the layout of attn.
 __global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
                                                            const float* __restrict__ attn, const float* __restrict__ dattn,
-                                                           float* __restrict__ ds, float* __restrict__ dtheta, PcmOffsets o,
-                                                           PcmGrid g, int F, int flags, int scale_mode) {
+                                                           float* __restrict__ ds, float* __restrict__ ds2,
+                                                           float* __restrict__ dtheta, PcmOffsets o, PcmGrid g, int F, int F_relu,
+                                                           int flags, int scale_mode) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.S) return;
     const int b = blockIdx.y;
@@ -104,13 +111,16 @@ __global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restri
     const float* a = attn + (int64_t)b * o.n * g.S + i;
     const float* da = dattn + (int64_t)b * o.n * g.S + i;
     float* s = ds + (int64_t)b * o.n * g.S + i;
-    // pass A: recompute the raw dots (parked in ds), sum_k a_k da_k, degree, sum of squares of the activated dots
+    // ds2 (split activation only, F_relu < F; host: no L2 normalisation then): the gradient w.r.t. the un-activated part
+    float* s2 = ds2 ? ds2 + (int64_t)b * o.n * g.S + i : nullptr;
+    // pass A: recompute the raw dots of the activated part (parked in ds), sum_k a_k da_k, degree, sum of squares of the
+    // activated dots
     float deg = 0.f, ada = 0.f, ss = 0.f;
     for (int e = 0; e < o.n; ++e) {
         int64_t j;
         float dot = 0.f;
         if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
-            for (int f = 0; f < F; ++f) dot = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], dot);
+            for (int f = 0; f < F_relu; ++f) dot = fmaf(th[(int64_t)f * g.S], ph[(int64_t)f * g.S + j], dot);
             deg += 1.f;
             const float u = (flags & PCM_RELU) ? fmaxf(dot, 0.f) : dot;
             ss = fmaf(u, u, ss);
@@ -143,17 +153,21 @@ __global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restri
             const float ae = a[(int64_t)e * g.S];
             const float dl = scale * ae * (da[(int64_t)e * g.S] - ada);      // w.r.t. the normalised, unscaled logit
             d = l2 ? (l2live ? (dl - (u / nrm) * vdv) / nrm : dl / nrm) : dl;
+            if (s2) s2[(int64_t)e * g.S] = d;                   // the un-activated part sees the logit's gradient as it is
             if ((flags & PCM_RELU) && !(dot > 0.f)) d = 0.f;
+        } else if (s2) {
+            s2[(int64_t)e * g.S] = 0.f;
         }
         s[(int64_t)e * g.S] = d;
     }
-    // dtheta[b,f,i] = sum_e ds_e * phi[b,f,i+o_e]
+    // dtheta[b,f,i] = sum_e ds_e * phi[b,f,i+o_e]   (ds2 for the feature planes outside the activation)
     float* dth = dtheta + (int64_t)b * F * g.S + i;
     for (int f = 0; f < F; ++f) {
+        const float* sf = (f < F_relu || !s2) ? s : s2;
         float acc = 0.f;
         for (int e = 0; e < o.n; ++e) {
             int64_t j;
-            if (pcm_neighbour(g, o, e, z, y, x, i, j)) acc = fmaf(s[(int64_t)e * g.S], ph[(int64_t)f * g.S + j], acc);
+            if (pcm_neighbour(g, o, e, z, y, x, i, j)) acc = fmaf(sf[(int64_t)e * g.S], ph[(int64_t)f * g.S + j], acc);
         }
         dth[(int64_t)f * g.S] = acc;
     }
@@ -161,10 +175,11 @@ __global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restri
 
 // Adjoint gather shared by dphi and dv:  out[b,c,j] = sum_e w[b,e,j-o_e] * src[b,c,j-o_e]  (j - o_e inside the grid)
 __global__ __launch_bounds__(256) void pcm_scatter_adjoint_kernel(const float* __restrict__ w, const float* __restrict__ src,
-                                                                  float* __restrict__ out, PcmOffsets o, PcmGrid g, int C) {
+                                                                  float* __restrict__ out, PcmOffsets o, PcmGrid g, int C,
+                                                                  int c_lo) {
     const int64_t jn = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (jn >= g.S) return;
-    const int c = blockIdx.y, b = blockIdx.z;
+    const int c = c_lo + blockIdx.y, b = blockIdx.z;      // channels [c_lo, c_lo + gridDim.y) of C
     const int x = (int)(jn % g.W), y = (int)((jn / g.W) % g.H), z = (int)(jn / ((int64_t)g.W * g.H));
     const float* wb = w + (int64_t)b * o.n * g.S;
     const float* sb = src + ((int64_t)b * C + c) * g.S;
@@ -243,34 +258,59 @@ static int pcm_setup(const int* offsets, int E, int D, int H, int W, PcmOffsets&
 
 using namespace dram;
 
-extern "C" int dram_pcm_attention_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
-                                      int scale_mode, float* attn, int B, int F, int D, int H, int W, void* stream) {
+extern "C" int dram_pcm_attention_split_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
+                                            int scale_mode, int F_relu, float* attn, int B, int F, int D, int H, int W,
+                                            void* stream) {
     DRAM_REQUIRE(theta && phi && attn, "pcm_attention_fwd: null pointer");
     DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0, "pcm_attention_fwd: bad dimensions");
     DRAM_REQUIRE((flags & ~3) == 0 && scale_mode >= 0 && scale_mode <= 2, "pcm_attention_fwd: unknown mode");
+    DRAM_REQUIRE(F_relu >= 0 && F_relu <= F && (F_relu == F || !(flags & PCM_L2NORM)),
+                 "pcm_attention_fwd: the activated part is F_relu = %d of %d feature planes (no L2 normalisation with a split)", F_relu, F);
     PcmOffsets o;
     PcmGrid g;
     if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_fwd")) return rc;
     hipLaunchKernelGGL(pcm_attn_fwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi,
-                       attn, o, g, F, flags, scale_mode);
+                       attn, o, g, F, F_relu, flags, scale_mode);
     return check_launch("pcm_attention_fwd");
 }
 
-extern "C" int dram_pcm_attention_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
-                                      const int* offsets, int E, int flags, int scale_mode, float* ds, float* dtheta,
-                                      float* dphi, int B, int F, int D, int H, int W, void* stream) {
+extern "C" int dram_pcm_attention_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
+                                      int scale_mode, float* attn, int B, int F, int D, int H, int W, void* stream) {
+    return dram_pcm_attention_split_fwd(theta, phi, offsets, E, flags, scale_mode, F, attn, B, F, D, H, W, stream);
+}
+
+extern "C" int dram_pcm_attention_split_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                                            const int* offsets, int E, int flags, int scale_mode, int F_relu, float* ds,
+                                            float* ds2, float* dtheta, float* dphi, int B, int F, int D, int H, int W,
+                                            void* stream) {
     DRAM_REQUIRE(theta && phi && attn && dattn && ds && dtheta && dphi, "pcm_attention_bwd: null pointer");
     DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0 && F <= 65535, "pcm_attention_bwd: bad dimensions");
     DRAM_REQUIRE((flags & ~3) == 0 && scale_mode >= 0 && scale_mode <= 2, "pcm_attention_bwd: unknown mode");
+    DRAM_REQUIRE(F_relu >= 0 && F_relu <= F && (F_relu == F || !(flags & PCM_L2NORM)),
+                 "pcm_attention_bwd: the activated part is F_relu = %d of %d feature planes (no L2 normalisation with a split)", F_relu, F);
+    const bool split = F_relu < F && (flags & PCM_RELU);      // (without an activation the two parts share one gradient)
+    DRAM_REQUIRE(!split || ds2, "pcm_attention_bwd: a split activation needs the second gradient buffer ds2");
     PcmOffsets o;
     PcmGrid g;
     if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_bwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pcm_attn_bwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, theta, phi, attn, dattn, ds,
-                       dtheta, o, g, F, flags, scale_mode);
+                       split ? ds2 : (float*)nullptr, dtheta, o, g, F, split ? F_relu : F, flags, scale_mode);
     // dphi[b,f,j] = sum_e ds[b,e,j-o_e] * theta[b,f,j-o_e]
-    hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), F, B), dim3(256), 0, st, ds, theta, dphi, o, g, F);
+    const int F1 = split ? F_relu : F;
+    if (F1 > 0)
+        hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), F1, B), dim3(256), 0, st, ds, theta, dphi, o, g, F, 0);
+    if (F1 < F)
+        hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), F - F1, B), dim3(256), 0, st, ds2, theta, dphi, o,
+                           g, F, F1);
     return check_launch("pcm_attention_bwd");
+}
+
+extern "C" int dram_pcm_attention_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                                      const int* offsets, int E, int flags, int scale_mode, float* ds, float* dtheta,
+                                      float* dphi, int B, int F, int D, int H, int W, void* stream) {
+    return dram_pcm_attention_split_bwd(theta, phi, attn, dattn, offsets, E, flags, scale_mode, F, ds, nullptr, dtheta, dphi, B, F,
+                                        D, H, W, stream);
 }
 
 extern "C" int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets, int E, float* out, int B, int C,
@@ -295,6 +335,6 @@ extern "C" int dram_pcm_aggregate_bwd(const float* attn, const float* v, const f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pcm_aggregate_dattn_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, dout, v, dattn, o, g, C);
     // dv[b,c,j] = sum_e attn[b,e,j-o_e] * dout[b,c,j-o_e]
-    hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), C, B), dim3(256), 0, st, attn, dout, dv, o, g, C);
+    hipLaunchKernelGGL(pcm_scatter_adjoint_kernel, dim3((unsigned)cdiv64(g.S, 256), C, B), dim3(256), 0, st, attn, dout, dv, o, g, C, 0);
     return check_launch("pcm_aggregate_bwd");
 }

@@ -76,6 +76,8 @@ SIGNATURES = {
     "dram_spatial_permute_flip": (I, [P, P, I, I, I, I, I, P, P, P]),
     "dram_pcm_attention_fwd": (I, [P, P, P, I, I, I, P, I, I, I, I, I, P]),
     "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
+    "dram_pcm_attention_split_fwd": (I, [P, P, P, I, I, I, I, P, I, I, I, I, I, P]),
+    "dram_pcm_attention_split_bwd": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_bwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, P]),
     # fused conv -> norm -> ReLU -> conv chains ("lazy" tensors)

@@ -744,31 +744,34 @@ class PcmAttentionFn(Function):
     (reference models.py: merge_func 259-331 inside compute_cross_x 365-397)."""
 
     @staticmethod
-    def forward(ctx, theta, phi, offsets, flags, scale_mode):
+    def forward(ctx, theta, phi, offsets, flags, scale_mode, f_relu=None):
         theta, phi = _chk(theta, "pcm theta", 5), _chk(phi, "pcm phi", 5)
         if theta.shape != phi.shape:
             raise ValueError(f"pcm attention: theta {tuple(theta.shape)} and phi {tuple(phi.shape)} differ")
         B, Fd, D, H, W = theta.shape
+        f_relu = Fd if f_relu is None else int(f_relu)      # feature planes inside the activation (the rest is added raw)
         arr, E = _offsets_arg(offsets)
         attn = torch.empty((B, E, D, H, W), dtype=torch.float32, device=theta.device)
-        call("dram_pcm_attention_fwd", _p(theta), _p(phi), arr, E, flags, scale_mode, _p(attn), B, Fd, D, H, W, _stream())
+        call("dram_pcm_attention_split_fwd", _p(theta), _p(phi), arr, E, flags, scale_mode, f_relu, _p(attn), B, Fd, D, H, W,
+             _stream())
         ctx.save_for_backward(theta, phi, attn)
-        ctx.cfg = (offsets, flags, scale_mode)
+        ctx.cfg = (offsets, flags, scale_mode, f_relu)
         return attn
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dattn):
         theta, phi, attn = ctx.saved_tensors
-        offsets, flags, scale_mode = ctx.cfg
+        offsets, flags, scale_mode, f_relu = ctx.cfg
         dattn = _chk(dattn, "pcm attention grad_output", 5)
         B, Fd, D, H, W = theta.shape
         arr, E = _offsets_arg(offsets)
         ds = torch.empty_like(attn)
+        ds2 = torch.empty_like(attn) if (f_relu < Fd and (flags & PCM_RELU)) else None
         dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
-        call("dram_pcm_attention_bwd", _p(theta), _p(phi), _p(attn), _p(dattn), arr, E, flags, scale_mode, _p(ds),
-             _p(dtheta), _p(dphi), B, Fd, D, H, W, _stream())
-        return dtheta, dphi, None, None, None
+        call("dram_pcm_attention_split_bwd", _p(theta), _p(phi), _p(attn), _p(dattn), arr, E, flags, scale_mode, f_relu, _p(ds),
+             _p(ds2), _p(dtheta), _p(dphi), B, Fd, D, H, W, _stream())
+        return dtheta, dphi, None, None, None, None
 
 
 class PcmAggregateFn(Function):
@@ -799,12 +802,30 @@ class PcmAggregateFn(Function):
         return dattn, dv, None
 
 
-def pcm_attention(theta, phi, offsets, merge_type):
+# merge types with a positional-encoding term (reference models.py:287-299): the same kernels on combined feature planes
+PCM_GEO_MERGES = ("scaled_dot_product_geo", "scaled_dot_product_geo_relu", "att_is_all")
+
+
+def pcm_attention(theta, phi, offsets, merge_type, geo_theta=None, geo_phi=None):
+    """merge_func (reference models.py:259-331) on the voxel grid.  geo_theta / geo_phi: the projected positional
+    encodings [B, geo_f_dim, D, H, W] that the geo merge types add to the appearance term."""
+    offsets = tuple(map(tuple, offsets))
+    if merge_type in PCM_GEO_MERGES:
+        if geo_theta is None or geo_phi is None:
+            raise ValueError(f"PCM merge_type {merge_type!r} needs the positional encodings (p_enc_dim > 0)")
+        if merge_type == "att_is_all":                  # (theta + geo_theta) . (phi + geo_phi), models.py:297-299
+            if theta.shape != geo_theta.shape:
+                raise ValueError(f"att_is_all: f_dim {theta.shape[1]} and geo_f_dim {geo_theta.shape[1]} must agree")
+            return PcmAttentionFn.apply(theta + geo_theta, phi + geo_phi, offsets, 0, 1)
+        th, ph = torch.cat([theta, geo_theta], 1), torch.cat([phi, geo_phi], 1)
+        if merge_type == "scaled_dot_product_geo":      # theta.phi + geo_theta.geo_phi: one dot over the stacked planes
+            return PcmAttentionFn.apply(th, ph, offsets, 0, 1)
+        return PcmAttentionFn.apply(th, ph, offsets, PCM_RELU, 1, theta.shape[1])     # relu(theta.phi) + geo_theta.geo_phi
     if merge_type not in PCM_MERGE_MODES:
-        raise NotImplementedError(f"PCM merge_type {merge_type!r}: only the dot-product family "
-                                  f"{sorted(PCM_MERGE_MODES)} is implemented on the device")
+        raise NotImplementedError(f"PCM merge_type {merge_type!r}: the dot-product family {sorted(PCM_MERGE_MODES)} and the "
+                                  f"geo family {list(PCM_GEO_MERGES)} are implemented on the device")
     flags, scale_mode = PCM_MERGE_MODES[merge_type]
-    return PcmAttentionFn.apply(theta, phi, tuple(map(tuple, offsets)), flags, scale_mode)
+    return PcmAttentionFn.apply(theta, phi, offsets, flags, scale_mode)
 
 
 def pcm_aggregate(attn, v, offsets):

@@ -229,8 +229,9 @@ class PCM(nn.Module):
     attention weights per (node, offset) and their weighted aggregation (csrc/pcm.hip).
 
     Implemented merge types: the dot-product family `dram_amd.functional.PCM_MERGE_MODES`
-    (incl. the shipped 'scaled_dot_product_relu'); the others (geo / l2 / cosine / heu*) raise
-    NotImplementedError at call time, like the reference does for unknown names."""
+    (incl. the shipped 'scaled_dot_product_relu') and the geo family `PCM_GEO_MERGES` (an appearance term
+    plus a term over sin/cos positional encodings, `build_geo_feature`); the others (l2 / cosine /
+    heu*) raise NotImplementedError at call time, like the reference does for unknown names."""
 
     def __init__(self, pool_size, in_ch, g_ch, f_dim, geo_f_dim, g_dim, non_local_iter, k_size,
                  merge_type='l2', self_loop=True, connectivity=2, residual=False, p_enc_dim=32):
@@ -271,6 +272,29 @@ class PCM(nn.Module):
                 self.geo_phi = Identity()
                 self.geo_f_dim = p_enc_dim
         self.graph = None           # the reference caches its DGLGraph here; we cache the offset list
+        self._geo_cache = {}
+
+    def build_geo_feature(self, x):
+        """models.py:194-219: sin/cos positional encoding of the voxel coordinates, p_enc_dim/3 channels per axis
+        (frequencies 1e-4^(2i/d)), the same for every sample; a constant of the grid, built once per shape with the
+        reference's own torch expressions on the host and kept on the device."""
+        spatial = tuple(int(v) for v in x.shape[-3:])
+        key = (spatial, x.device)
+        if key not in self._geo_cache:
+            if self.p_enc_dim % (2 * len(spatial)) != 0:
+                raise ValueError("Cannot use sin/cos positional encoding with "
+                                 "odd dimension (got dim={:d})".format(self.p_enc_dim))
+            p = torch.ones(spatial).nonzero().float().view(*spatial, len(spatial))
+            pe = torch.zeros(self.p_enc_dim, *spatial)
+            d_model = int(self.p_enc_dim / len(spatial))
+            div = torch.pow(1e-4, torch.arange(0., d_model, 2) / d_model)
+            for d in range(len(spatial)):
+                start, end = d * d_model, (d + 1) * d_model
+                arg = p[..., d].expand(len(div), *spatial) * div.view(len(div), *([1] * len(spatial)))
+                pe[start:end:2] = torch.sin(arg)
+                pe[(start + 1):end:2] = torch.cos(arg)
+            self._geo_cache[key] = pe.unsqueeze(0).to(x.device)
+        return self._geo_cache[key].expand(x.shape[0], -1, *spatial)
 
     def init_graph(self, spatial_size=None, k_size=None):
         """Neighbour offsets (dz,dy,dx) of models.py:230-232 (+ remove_self_loop, 257-258)."""
@@ -294,7 +318,14 @@ class PCM(nn.Module):
         offsets = self.graph
         theta = _channel_linear(self.theta, f)
         phi = _channel_linear(self.phi, f)
-        attn = HF.pcm_attention(theta, phi, offsets, self.merge_type)     # f is fixed over the iterations
+        geo_theta = geo_phi = None
+        if self.merge_type in HF.PCM_GEO_MERGES:
+            if self.p_enc_dim <= 0:
+                raise ValueError(f"PCM merge_type {self.merge_type!r} needs p_enc_dim > 0")
+            geo = self.build_geo_feature(f).contiguous()        # detached by construction (models.py:343)
+            geo_theta = _channel_linear(self.geo_theta, geo)
+            geo_phi = _channel_linear(self.geo_phi, geo)
+        attn = HF.pcm_attention(theta, phi, offsets, self.merge_type, geo_theta, geo_phi)   # f is fixed over the iterations
         for _ in range(self.non_local_iter):
             y = HF.pcm_aggregate(attn, _channel_linear(self.G, cam), offsets)
             refined_cam = _channel_linear(self.r, y)

@@ -274,7 +274,7 @@ int dram_intreg_loss_bwd(const float* dense, const float* refined, const float* 
                          void* stream);
 
 /* ---- PCM local attention on the voxel grid: dram/models.py PCM.init_graph 221-258 (the
- *      neighbour graph becomes E stencil offsets), merge_func 259-331 (dot-product family), compute_cross_x
+ *      neighbour graph becomes E stencil offsets), merge_func 259-331 (dot-product and geo families), compute_cross_x
  *      365-397, forward / update_all 333-363.
  * theta, phi: [B,F,D,H,W]; offsets: HOST array of E*3 ints (dz,dy,dx), E <= 128; node i receives from
  * i + offset (in-grid offsets only).  attn: [B,E,D,H,W] = softmax over the node's edges of
@@ -288,6 +288,16 @@ int dram_pcm_attention_fwd(const float* theta, const float* phi, const int* offs
 int dram_pcm_attention_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
                            const int* offsets, int E, int flags, int scale_mode, float* ds, float* dtheta,
                            float* dphi, int B, int F, int D, int H, int W, void* stream);
+/* The geo variants of merge_func (models.py:287-299: scaled_dot_product_geo, scaled_dot_product_geo_relu, att_is_all) add a
+ * positional-encoding term to the appearance term.  On feature planes concatenated as [appearance ; positional] they are
+ * the kernels above with the activation confined to the first F_relu planes:
+ *     logit = act(sum_{f < F_relu} theta_f phi_f) + sum_{f >= F_relu} theta_f phi_f       (F_relu == F: the plain forms).
+ * ds2: second scratch [B,E,D,H,W], needed when F_relu < F and DRAM_PCM_RELU is set (NULL otherwise). */
+int dram_pcm_attention_split_fwd(const float* theta, const float* phi, const int* offsets, int E, int flags,
+                                 int scale_mode, int F_relu, float* attn, int B, int F, int D, int H, int W, void* stream);
+int dram_pcm_attention_split_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                                 const int* offsets, int E, int flags, int scale_mode, int F_relu, float* ds, float* ds2,
+                                 float* dtheta, float* dphi, int B, int F, int D, int H, int W, void* stream);
 /* out[b,c,i] = sum_e attn[b,e,i] * v[b,c,i+offset_e]   (torch.matmul(f_sm, x_g), models.py:394) */
 int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets, int E, float* out,
                            int B, int C, int D, int H, int W, void* stream);

@@ -515,6 +515,24 @@ ST_DRAM_REF_ATT_MODEL = dict(ST_DRAM_REF_MODEL, **{     # dram/exp_settings/st_d
 })
 
 PCM_DOT_MERGES = ("sm", "scaled_dot_product", "scaled_dot_product_relu", "smrelu", "smscaled", "l2sm", "l2smrelu")
+PCM_GEO_MERGES = ("scaled_dot_product_geo", "scaled_dot_product_geo_relu", "att_is_all")     # models.py:287-299
+
+
+def pcm_geo_feature(p_enc_dim, spatial, dtype=torch.float32):
+    """PCM.build_geo_feature (models.py:194-219) for one sample: [p_enc_dim, D, H, W]."""
+    spatial = tuple(spatial)
+    if p_enc_dim % (2 * len(spatial)) != 0:
+        raise ValueError("Cannot use sin/cos positional encoding with odd dimension (got dim={:d})".format(p_enc_dim))
+    pos = torch.ones(spatial).nonzero().to(dtype).view(*spatial, len(spatial))
+    pe = torch.zeros(p_enc_dim, *spatial, dtype=dtype)
+    d_model = int(p_enc_dim / len(spatial))
+    div = torch.pow(1e-4, torch.arange(0., d_model, 2) / d_model).to(dtype)
+    for d in range(len(spatial)):
+        start, end = d * d_model, (d + 1) * d_model
+        arg = pos[..., d].expand(len(div), *spatial) * div.view(len(div), *([1] * len(spatial)))
+        pe[start:end:2] = torch.sin(arg)
+        pe[(start + 1):end:2] = torch.cos(arg)
+    return pe
 
 
 def pcm_offsets(k_size=3, connectivity=2, self_loop=True):
@@ -557,11 +575,11 @@ def _lin(p, name, x):
 
 
 def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type="scaled_dot_product_relu",
-                non_local_iter=1, residual=False):
-    """PCM.forward (models.py:333-363) with p_enc_dim == 0, as dense tensor algebra.
-    p: {"theta.weight", "theta.bias", "phi.*", "G.*", "r.*"} (absent = Identity, models.py:169-183).
-    cam [B, g_ch, D, H, W], f [B, in_ch, D, H, W] -> refined cam [B, g_ch, D, H, W]."""
-    if merge_type not in PCM_DOT_MERGES:
+                non_local_iter=1, residual=False, p_enc_dim=0):
+    """PCM.forward (models.py:333-363) as dense tensor algebra.
+    p: {"theta.weight", "theta.bias", "phi.*", "G.*", "r.*", "geo_theta.*", "geo_phi.*"} (absent = Identity,
+    models.py:169-192).  cam [B, g_ch, D, H, W], f [B, in_ch, D, H, W] -> refined cam [B, g_ch, D, H, W]."""
+    if merge_type not in PCM_DOT_MERGES + PCM_GEO_MERGES:
         raise NotImplementedError(merge_type)
     B, _, D, H, W = f.shape
     offs = pcm_offsets(k_size, connectivity, self_loop)
@@ -574,8 +592,20 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
         return tp[..., R + o[0]:R + o[0] + D, R + o[1]:R + o[1] + H, R + o[2]:R + o[2] + W]
     valid = torch.cat([shifted(ones, o) for o in offs], dim=1)              # [1, E, D, H, W]
     deg = valid.sum(1, keepdim=True)
-    logits = torch.stack([(th * shifted(ph, o)).sum(1) for o in offs], dim=1)   # [B, E, D, H, W]
-    a = _pcm_logits(merge_type, logits, valid, deg)
+    if merge_type in PCM_GEO_MERGES:                                        # models.py:287-299
+        geo = pcm_geo_feature(p_enc_dim, (D, H, W), f.dtype).unsqueeze(0).expand(B, -1, D, H, W)
+        gth, gph = _lin(p, "geo_theta", geo), _lin(p, "geo_phi", geo)
+        if merge_type == "att_is_all":
+            logits = torch.stack([((th + gth) * shifted(ph + gph, o)).sum(1) for o in offs], dim=1)
+        else:
+            app = torch.stack([(th * shifted(ph, o)).sum(1) for o in offs], dim=1)
+            if merge_type == "scaled_dot_product_geo_relu":
+                app = F.relu(app)
+            logits = app + torch.stack([(gth * shifted(gph, o)).sum(1) for o in offs], dim=1)
+        a = _pcm_logits("scaled_dot_product", logits, valid, deg)
+    else:
+        logits = torch.stack([(th * shifted(ph, o)).sum(1) for o in offs], dim=1)   # [B, E, D, H, W]
+        a = _pcm_logits(merge_type, logits, valid, deg)
     for _ in range(non_local_iter):
         g = _lin(p, "G", cam)                                                # [B, g_dim, D, H, W]
         y = sum(a[:, e:e + 1] * shifted(g, o) for e, o in enumerate(offs))
@@ -585,7 +615,7 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
 
 
 def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
-                        merge_type="scaled_dot_product_relu"):
+                        merge_type="scaled_dot_product_relu", p_enc_dim=0):
     """The same, written the way DGL executes it: one node at a time, its mailbox = the in-grid
     neighbours (init_graph's interior/side split collapses to "neighbours inside the grid"),
     compute_cross_x's permutes and matmuls spelled out (models.py:365-397).  Tiny grids only."""
@@ -593,6 +623,7 @@ def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
     offs = pcm_offsets(k_size, connectivity, self_loop)
     out = torch.zeros_like(cam)
     lin = lambda name, x: x if (name + ".weight") not in p else F.linear(x, p[name + ".weight"], p[name + ".bias"])
+    geo = pcm_geo_feature(p_enc_dim, (D, H, W), f.dtype).unsqueeze(0).expand(B, -1, D, H, W) if p_enc_dim > 0 else None
     for z in range(D):
         for y in range(H):
             for x in range(W):
@@ -603,6 +634,17 @@ def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
                 x_phi = lin("phi", f_agg).permute(1, 2, 0)                                # [B, F, E]
                 x_theta = lin("theta", f[:, :, z, y, x]).unsqueeze(1)                     # [B, 1, F]
                 fm = torch.matmul(x_theta, x_phi)                                         # [B, 1, E]
+                if merge_type in PCM_GEO_MERGES:                                          # merge_func, models.py:287-299
+                    g_agg = torch.stack([geo[:, :, q[0], q[1], q[2]] for q in nb], 0)     # [E, B, p_enc]
+                    x_gphi = lin("geo_phi", g_agg).permute(1, 2, 0)                       # [B, Fg, E]
+                    x_gtheta = lin("geo_theta", geo[:, :, z, y, x]).unsqueeze(1)          # [B, 1, Fg]
+                    if merge_type == "att_is_all":
+                        fm = torch.matmul(x_theta + x_gtheta, x_phi + x_gphi)
+                    else:
+                        if merge_type == "scaled_dot_product_geo_relu":
+                            fm = F.relu(fm)
+                        fm = fm + torch.matmul(x_gtheta, x_gphi)
+                    fm = fm / np.sqrt(fm.shape[-1])
                 if merge_type in ("scaled_dot_product_relu", "smrelu", "l2smrelu"):
                     fm = F.relu(fm)
                 if merge_type in ("l2sm", "l2smrelu"):

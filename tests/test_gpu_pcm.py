@@ -63,6 +63,47 @@ def test_pcm_module_matches_oracle(merge, shape, self_loop, iters, residual, con
         assert err <= TOL * max(scale, 1e-30), (k, err, scale)
 
 
+@pytest.mark.parametrize("merge", O.PCM_GEO_MERGES)
+@pytest.mark.parametrize("shape,self_loop,iters,residual,conn,geo_f", [
+    ((5, 4, 7), False, 1, False, 2, 4), ((1, 2, 3), True, 1, False, 2, 4), ((6, 6, 6), False, 2, True, 2, 4), ((4, 5, 6), True, 1, False, 3, 0)])
+def test_pcm_geo_merges_match_oracle(merge, shape, self_loop, iters, residual, conn, geo_f):
+    """The geo family of merge_func (models.py:287-299): appearance term + positional-encoding term (sin/cos encodings of
+    build_geo_feature projected by geo_theta / geo_phi); geo_f = 0: Identity projections.  PARITY UNPINNED like all of
+    PCM; checked against the oracle's fp64 restatement, values and every gradient (geo_theta / geo_phi included)."""
+    import models
+    torch.manual_seed(5)
+    B, C, G, Gd, P = 2, 7, 2, 3, 12
+    Fd = 4 if geo_f else P              # att_is_all adds the two feature vectors: f_dim == geo_f_dim
+    if merge != "att_is_all" and not geo_f:
+        Fd = 5
+    m = models.PCM(shape, C, G, Fd, geo_f, Gd, iters, 3, merge_type=merge, self_loop=self_loop, connectivity=conn,
+                   residual=residual, p_enc_dim=P)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)
+    g = torch.Generator().manual_seed(6)
+    cam = torch.randn((B, G) + shape, generator=g)
+    f = torch.randn((B, C) + shape, generator=g)
+    gout = torch.randn((B, G) + shape, generator=g)
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    cam64, f64 = cam.double().requires_grad_(True), f.double().requires_grad_(True)
+    ref = O.pcm_forward(p64, cam64, f64, 3, conn, self_loop, merge, iters, residual, p_enc_dim=P)
+    (ref * gout.double()).sum().backward()
+    m = m.cuda()
+    camg, fg = cam.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
+    out = m(camg, fg)
+    (out * gout.cuda()).sum().backward()
+    assert rel(out, ref) <= TOL
+    assert rel(camg.grad, cam64.grad) <= TOL
+    assert rel(fg.grad, f64.grad) <= TOL
+    scale = max(v.grad.abs().max().item() for v in p64.values() if v.grad is not None)
+    names = dict(m.named_parameters())
+    assert (geo_f == 0) or {"geo_theta.weight", "geo_phi.weight"} <= set(names)
+    for k, p in names.items():
+        err = (p.grad.detach().cpu().double() - p64[k].grad).abs().max().item()
+        assert err <= TOL * max(scale, 1e-30), (k, err, scale)
+
+
 def _oracle_pcm(p, cam, f, conn, self_loop, merge, iters, residual):
     return O.pcm_forward(p, cam, f, 3, conn, self_loop, merge, iters, residual)
 

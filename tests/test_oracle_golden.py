@@ -187,6 +187,30 @@ def test_pcm_dense_restatement_equals_literal_one(merge, self_loop):
     assert len(O.pcm_offsets(3, 2, False)) == 18 and len(O.pcm_offsets(3, 1, True)) == 7   # st_dram_ref_att: 18
 
 
+@pytest.mark.parametrize("merge", O.PCM_GEO_MERGES)
+@pytest.mark.parametrize("geo_f", [4, 0])
+def test_pcm_geo_dense_restatement_equals_literal_one(merge, geo_f):
+    """PARITY UNPINNED (DGL absent): the geo family of merge_func (models.py:287-299) in the two restatements; the
+    positional encoding against the reference's formula evaluated by hand at one voxel."""
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    P = 12
+    Fd = 4 if geo_f else (P if merge == "att_is_all" else 5)
+    p = {"theta.weight": r(Fd, 5), "theta.bias": r(Fd), "phi.weight": r(Fd, 5), "phi.bias": r(Fd),
+         "G.weight": r(3, 2), "G.bias": r(3), "r.weight": r(2, 3), "r.bias": r(2)}
+    if geo_f:
+        p.update({"geo_theta.weight": r(geo_f, P), "geo_theta.bias": r(geo_f), "geo_phi.weight": r(geo_f, P), "geo_phi.bias": r(geo_f)})
+    for shape in [(4, 3, 5), (1, 2, 3)]:
+        cam, f = r(2, 2, *shape), r(2, 5, *shape)
+        a = O.pcm_forward(p, cam, f, 3, 2, False, merge, p_enc_dim=P)
+        b = O.pcm_forward_literal(p, cam, f, 3, 2, False, merge, p_enc_dim=P)
+        assert (a - b).abs().max().item() < 1e-10
+    pe = O.pcm_geo_feature(P, (4, 3, 5), torch.float64)          # d_model = 4 per axis: sin, cos at frequencies 1, 1e-2
+    z, y, x = 3, 1, 4
+    want = [fn(c * w) for c in (z, y, x) for w in (1.0, 1e-2) for fn in (np.sin, np.cos)]
+    assert np.allclose(pe[:, z, y, x].numpy(), want, rtol=1e-6, atol=1e-7)     # (the frequencies are fp32 powers, as in the reference)
+
+
 def test_loss_two_outputs(golden_dir):
     z = _load(golden_dir, "loss2")
     dense, refined = _t(z["dense"]).requires_grad_(True), _t(z["refined"]).requires_grad_(True)
