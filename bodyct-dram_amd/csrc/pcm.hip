@@ -173,6 +173,160 @@ __global__ __launch_bounds__(256) void pcm_attn_bwd_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------- sum-normalised merges (cosine, heu1, heu2)
+// merge_func's variants without a softmax (models.py:300-302, 307-320): a per-edge similarity v_e >= ... of (theta_i, phi_j),
+//     cosine: v = sum_f (theta_f / max(|theta|, 1e-8)) (phi_f / max(|phi|, 1e-8))          (F.cosine_similarity)
+//     heu1:   u = theta.phi / (1 + sum_f |theta_f - phi_f|),  v = u if u >= 0.03 else 0     (the mask carries no gradient)
+//     heu2:   v = relu(u)
+// normalised by the sum over the node's edges, a_e = v_e / (eps + sum_k v_k), eps = 0 (cosine) / 1e-7 (heu).
+enum { PCM_SUM_COSINE = 0, PCM_SUM_HEU1 = 1, PCM_SUM_HEU2 = 2 };
+constexpr int PCM_SUM_MAXF = 64;
+constexpr float PCM_COS_EPS = 1e-8f;
+
+// similarity of one (node, neighbour) pair and what its derivative needs: aux0 = |theta| clamp (cosine) / 1 + L1 (heu),
+// aux1 = |phi_j| clamp (cosine) / u (heu); gate = dv/du of heu (1 / 0)
+__device__ __forceinline__ float pcm_sum_value(int mode, const float* th, const float* phj, int64_t S, int F, float& aux0,
+                                               float& aux1, float& gate) {
+    float dot = 0.f;
+    if (mode == PCM_SUM_COSINE) {
+        float tt = 0.f, pp = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float t = th[(int64_t)f * S], q = phj[(int64_t)f * S];
+            dot = fmaf(t, q, dot); tt = fmaf(t, t, tt); pp = fmaf(q, q, pp);
+        }
+        aux0 = fmaxf(sqrtf(tt), PCM_COS_EPS);
+        aux1 = fmaxf(sqrtf(pp), PCM_COS_EPS);
+        gate = 1.f;
+        return dot / (aux0 * aux1);
+    }
+    float l1 = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float t = th[(int64_t)f * S], q = phj[(int64_t)f * S];
+        dot = fmaf(t, q, dot); l1 += fabsf(t - q);
+    }
+    aux0 = 1.f + l1;
+    const float u = dot / aux0;
+    aux1 = u;
+    gate = mode == PCM_SUM_HEU1 ? (u < 0.03f ? 0.f : 1.f) : (u > 0.f ? 1.f : 0.f);
+    return gate * u;
+}
+
+__global__ __launch_bounds__(256) void pcm_attn_sum_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                               float* __restrict__ attn, PcmOffsets o, PcmGrid g, int F, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* th = theta + (int64_t)b * F * g.S + i;
+    const float* ph = phi + (int64_t)b * F * g.S;
+    float* a = attn + (int64_t)b * o.n * g.S + i;
+    float sum = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float v = 0.f, a0, a1, gt;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) v = pcm_sum_value(mode, th, ph + j, g.S, F, a0, a1, gt);
+        sum += v;
+        a[(int64_t)e * g.S] = v;
+    }
+    const float inv = 1.f / (sum + (mode == PCM_SUM_COSINE ? 0.f : 1e-7f));
+    for (int e = 0; e < o.n; ++e) a[(int64_t)e * g.S] *= inv;
+}
+
+// ds[b,e,i] = d loss / d v_e (through the normalisation); dtheta from it
+__global__ __launch_bounds__(256) void pcm_attn_sum_bwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                               const float* __restrict__ attn, const float* __restrict__ dattn,
+                                                               float* __restrict__ ds, float* __restrict__ dtheta, PcmOffsets o,
+                                                               PcmGrid g, int F, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H), z = (int)(i / ((int64_t)g.W * g.H));
+    const float* th = theta + (int64_t)b * F * g.S + i;
+    const float* ph = phi + (int64_t)b * F * g.S;
+    const float* a = attn + (int64_t)b * o.n * g.S + i;
+    const float* da = dattn + (int64_t)b * o.n * g.S + i;
+    float* s = ds + (int64_t)b * o.n * g.S + i;
+    float acc[PCM_SUM_MAXF];
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    float sum = 0.f, ada = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float a0, a1, gt;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
+            sum += pcm_sum_value(mode, th, ph + j, g.S, F, a0, a1, gt);
+            ada = fmaf(a[(int64_t)e * g.S], da[(int64_t)e * g.S], ada);
+        }
+    }
+    const float invT = 1.f / (sum + (mode == PCM_SUM_COSINE ? 0.f : 1e-7f));
+    for (int e = 0; e < o.n; ++e) {
+        int64_t j;
+        float dv = 0.f;
+        if (pcm_neighbour(g, o, e, z, y, x, i, j)) {
+            float a0, a1, gt;
+            const float v = pcm_sum_value(mode, th, ph + j, g.S, F, a0, a1, gt);
+            dv = (da[(int64_t)e * g.S] - ada) * invT;
+            const float* phj = ph + j;
+            if (mode == PCM_SUM_COSINE) {       // dv/dtheta_f = (phi^_f - v theta^_f) / c_theta  (theta^ = theta / c_theta; no v term under the clamp)
+                float tt = 0.f;
+                for (int f = 0; f < F; ++f) tt = fmaf(th[(int64_t)f * g.S], th[(int64_t)f * g.S], tt);
+                const float live = sqrtf(tt) > PCM_COS_EPS ? 1.f : 0.f;
+                for (int f = 0; f < F; ++f)
+                    acc[f] = fmaf(dv, (phj[(int64_t)f * g.S] / a1 - live * v * th[(int64_t)f * g.S] / a0) / a0, acc[f]);
+            } else {                            // du/dtheta_f = (phi_f - u sgn(theta_f - phi_f)) / (1 + L1)
+                const float du = dv * gt / a0;
+                for (int f = 0; f < F; ++f) {
+                    const float t = th[(int64_t)f * g.S], q = phj[(int64_t)f * g.S];
+                    const float sg = t > q ? 1.f : (t < q ? -1.f : 0.f);
+                    acc[f] = fmaf(du, q - a1 * sg, acc[f]);
+                }
+            }
+        }
+        s[(int64_t)e * g.S] = dv;
+    }
+    float* dth = dtheta + (int64_t)b * F * g.S + i;
+    for (int f = 0; f < F; ++f) dth[(int64_t)f * g.S] = acc[f];
+}
+
+// dphi[b,f,j] = sum over the edges (i -> j = i + o_e) of ds[b,e,i] * d v_e(i) / d phi_f(j): gather at j, pair values recomputed
+__global__ __launch_bounds__(256) void pcm_attn_sum_dphi_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                                const float* __restrict__ ds, float* __restrict__ dphi, PcmOffsets o,
+                                                                PcmGrid g, int F, int mode) {
+    const int64_t jn = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (jn >= g.S) return;
+    const int b = blockIdx.y;
+    const int x = (int)(jn % g.W), y = (int)((jn / g.W) % g.H), z = (int)(jn / ((int64_t)g.W * g.H));
+    const float* thb = theta + (int64_t)b * F * g.S;
+    const float* phj = phi + (int64_t)b * F * g.S + jn;
+    const float* sb = ds + (int64_t)b * o.n * g.S;
+    float acc[PCM_SUM_MAXF];
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    for (int e = 0; e < o.n; ++e) {
+        const int zz = z - o.dz[e], yy = y - o.dy[e], xx = x - o.dx[e];
+        if (!((unsigned)zz < (unsigned)g.D && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)) continue;
+        const int64_t i = jn - (((int64_t)o.dz[e] * g.H + o.dy[e]) * g.W + o.dx[e]);
+        const float dv = sb[(int64_t)e * g.S + i];
+        const float* th = thb + i;
+        float a0, a1, gt;
+        const float v = pcm_sum_value(mode, th, phj, g.S, F, a0, a1, gt);
+        if (mode == PCM_SUM_COSINE) {           // dv/dphi_f = (theta^_f - v phi^_f) / c_phi
+            float pp = 0.f;
+            for (int f = 0; f < F; ++f) pp = fmaf(phj[(int64_t)f * g.S], phj[(int64_t)f * g.S], pp);
+            const float live = sqrtf(pp) > PCM_COS_EPS ? 1.f : 0.f;
+            for (int f = 0; f < F; ++f)
+                acc[f] = fmaf(dv, (th[(int64_t)f * g.S] / a0 - live * v * phj[(int64_t)f * g.S] / a1) / a1, acc[f]);
+        } else {                                // du/dphi_f = (theta_f + u sgn(theta_f - phi_f)) / (1 + L1)
+            const float du = dv * gt / a0;
+            for (int f = 0; f < F; ++f) {
+                const float t = th[(int64_t)f * g.S], q = phj[(int64_t)f * g.S];
+                const float sg = t > q ? 1.f : (t < q ? -1.f : 0.f);
+                acc[f] = fmaf(du, t + a1 * sg, acc[f]);
+            }
+        }
+    }
+    float* o_ = dphi + (int64_t)b * F * g.S + jn;
+    for (int f = 0; f < F; ++f) o_[(int64_t)f * g.S] = acc[f];
+}
+
 // Adjoint gather shared by dphi and dv:  out[b,c,j] = sum_e w[b,e,j-o_e] * src[b,c,j-o_e]  (j - o_e inside the grid)
 __global__ __launch_bounds__(256) void pcm_scatter_adjoint_kernel(const float* __restrict__ w, const float* __restrict__ src,
                                                                   float* __restrict__ out, PcmOffsets o, PcmGrid g, int C,
@@ -311,6 +465,35 @@ extern "C" int dram_pcm_attention_bwd(const float* theta, const float* phi, cons
                                       float* dphi, int B, int F, int D, int H, int W, void* stream) {
     return dram_pcm_attention_split_bwd(theta, phi, attn, dattn, offsets, E, flags, scale_mode, F, ds, nullptr, dtheta, dphi, B, F,
                                         D, H, W, stream);
+}
+
+extern "C" int dram_pcm_attention_sum_fwd(const float* theta, const float* phi, const int* offsets, int E, int mode,
+                                          float* attn, int B, int F, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(theta && phi && attn, "pcm_attention_sum_fwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0 && F <= PCM_SUM_MAXF, "pcm_attention_sum_fwd: bad dimensions (1..%d feature planes)", PCM_SUM_MAXF);
+    DRAM_REQUIRE(mode >= 0 && mode <= 2, "pcm_attention_sum_fwd: unknown mode");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_sum_fwd")) return rc;
+    hipLaunchKernelGGL(pcm_attn_sum_fwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi,
+                       attn, o, g, F, mode);
+    return check_launch("pcm_attention_sum_fwd");
+}
+
+extern "C" int dram_pcm_attention_sum_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
+                                          const int* offsets, int E, int mode, float* ds, float* dtheta, float* dphi, int B,
+                                          int F, int D, int H, int W, void* stream) {
+    DRAM_REQUIRE(theta && phi && attn && dattn && ds && dtheta && dphi, "pcm_attention_sum_bwd: null pointer");
+    DRAM_REQUIRE(B > 0 && B <= 65535 && F > 0 && F <= PCM_SUM_MAXF, "pcm_attention_sum_bwd: bad dimensions (1..%d feature planes)", PCM_SUM_MAXF);
+    DRAM_REQUIRE(mode >= 0 && mode <= 2, "pcm_attention_sum_bwd: unknown mode");
+    PcmOffsets o;
+    PcmGrid g;
+    if (int rc = pcm_setup(offsets, E, D, H, W, o, g, "pcm_attention_sum_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pcm_attn_sum_bwd_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, theta, phi, attn, dattn, ds,
+                       dtheta, o, g, F, mode);
+    hipLaunchKernelGGL(pcm_attn_sum_dphi_kernel, dim3((unsigned)cdiv64(g.S, 256), B), dim3(256), 0, st, theta, phi, ds, dphi, o, g, F, mode);
+    return check_launch("pcm_attention_sum_bwd");
 }
 
 extern "C" int dram_pcm_aggregate_fwd(const float* attn, const float* v, const int* offsets, int E, float* out, int B, int C,

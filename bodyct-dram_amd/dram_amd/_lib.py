@@ -78,6 +78,8 @@ SIGNATURES = {
     "dram_pcm_attention_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_attention_split_fwd": (I, [P, P, P, I, I, I, I, P, I, I, I, I, I, P]),
     "dram_pcm_attention_split_bwd": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, I, I, I, I, I, P]),
+    "dram_pcm_attention_sum_fwd": (I, [P, P, P, I, I, P, I, I, I, I, I, P]),
+    "dram_pcm_attention_sum_bwd": (I, [P, P, P, P, P, I, I, P, P, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_fwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_pcm_aggregate_bwd": (I, [P, P, P, P, I, P, P, I, I, I, I, I, P]),
     # fused conv -> norm -> ReLU -> conv chains ("lazy" tensors)

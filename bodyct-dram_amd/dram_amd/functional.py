@@ -774,6 +774,43 @@ class PcmAttentionFn(Function):
         return dtheta, dphi, None, None, None, None
 
 
+# merge types normalised by the sum over a node's edges instead of a softmax (reference models.py:300-302, 307-320)
+PCM_SUM_MERGES = {"cosine": 0, "heu1": 1, "heu2": 2}
+
+
+class PcmAttentionSumFn(Function):
+    """attn[b,e,i] = v_e / (eps + sum_k v_k) over node i's in-grid neighbours with v = the cosine similarity of
+    (theta_i, phi_(i+o_e)) / the heuristic similarity theta.phi / (1 + |theta - phi|_1), masked below 0.03 (heu1, the mask
+    carries no gradient) or rectified (heu2)."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, offsets, mode):
+        theta, phi = _chk(theta, "pcm theta", 5), _chk(phi, "pcm phi", 5)
+        if theta.shape != phi.shape:
+            raise ValueError(f"pcm attention: theta {tuple(theta.shape)} and phi {tuple(phi.shape)} differ")
+        B, Fd, D, H, W = theta.shape
+        arr, E = _offsets_arg(offsets)
+        attn = torch.empty((B, E, D, H, W), dtype=torch.float32, device=theta.device)
+        call("dram_pcm_attention_sum_fwd", _p(theta), _p(phi), arr, E, mode, _p(attn), B, Fd, D, H, W, _stream())
+        ctx.save_for_backward(theta, phi, attn)
+        ctx.cfg = (offsets, mode)
+        return attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dattn):
+        theta, phi, attn = ctx.saved_tensors
+        offsets, mode = ctx.cfg
+        dattn = _chk(dattn, "pcm attention grad_output", 5)
+        B, Fd, D, H, W = theta.shape
+        arr, E = _offsets_arg(offsets)
+        ds = torch.empty_like(attn)
+        dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
+        call("dram_pcm_attention_sum_bwd", _p(theta), _p(phi), _p(attn), _p(dattn), arr, E, mode, _p(ds), _p(dtheta), _p(dphi),
+             B, Fd, D, H, W, _stream())
+        return dtheta, dphi, None, None
+
+
 class PcmAggregateFn(Function):
     """out[b,c,i] = sum_e attn[b,e,i] * v[b,c,i+o_e]  (torch.matmul(f_sm, x_g), reference models.py:394)."""
 
@@ -821,9 +858,13 @@ def pcm_attention(theta, phi, offsets, merge_type, geo_theta=None, geo_phi=None)
         if merge_type == "scaled_dot_product_geo":      # theta.phi + geo_theta.geo_phi: one dot over the stacked planes
             return PcmAttentionFn.apply(th, ph, offsets, 0, 1)
         return PcmAttentionFn.apply(th, ph, offsets, PCM_RELU, 1, theta.shape[1])     # relu(theta.phi) + geo_theta.geo_phi
+    if merge_type in PCM_SUM_MERGES:
+        return PcmAttentionSumFn.apply(theta, phi, offsets, PCM_SUM_MERGES[merge_type])
     if merge_type not in PCM_MERGE_MODES:
-        raise NotImplementedError(f"PCM merge_type {merge_type!r}: the dot-product family {sorted(PCM_MERGE_MODES)} and the "
-                                  f"geo family {list(PCM_GEO_MERGES)} are implemented on the device")
+        # ('l2', models.py:260-262, subtracts [.., 1, f_dim] and [.., f_dim, edges] tensors: it only broadcasts when f_dim equals
+        #  the number of edges, and then weights every edge per feature -- not provided)
+        raise NotImplementedError(f"PCM merge_type {merge_type!r}: the dot-product family {sorted(PCM_MERGE_MODES)}, the "
+                                  f"geo family {list(PCM_GEO_MERGES)} and {sorted(PCM_SUM_MERGES)} are implemented on the device")
     flags, scale_mode = PCM_MERGE_MODES[merge_type]
     return PcmAttentionFn.apply(theta, phi, offsets, flags, scale_mode)
 

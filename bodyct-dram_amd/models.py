@@ -229,9 +229,10 @@ class PCM(nn.Module):
     attention weights per (node, offset) and their weighted aggregation (csrc/pcm.hip).
 
     Implemented merge types: the dot-product family `dram_amd.functional.PCM_MERGE_MODES`
-    (incl. the shipped 'scaled_dot_product_relu') and the geo family `PCM_GEO_MERGES` (an appearance term
-    plus a term over sin/cos positional encodings, `build_geo_feature`); the others (l2 / cosine /
-    heu*) raise NotImplementedError at call time, like the reference does for unknown names."""
+    (incl. the shipped 'scaled_dot_product_relu'), the geo family `PCM_GEO_MERGES` (an appearance term
+    plus a term over sin/cos positional encodings, `build_geo_feature`) and the sum-normalised
+    `PCM_SUM_MERGES` (cosine, heu1, heu2); 'l2' (which only broadcasts when f_dim equals the number of
+    edges) raises NotImplementedError at call time, like the reference does for unknown names."""
 
     def __init__(self, pool_size, in_ch, g_ch, f_dim, geo_f_dim, g_dim, non_local_iter, k_size,
                  merge_type='l2', self_loop=True, connectivity=2, residual=False, p_enc_dim=32):

@@ -516,6 +516,7 @@ ST_DRAM_REF_ATT_MODEL = dict(ST_DRAM_REF_MODEL, **{     # dram/exp_settings/st_d
 
 PCM_DOT_MERGES = ("sm", "scaled_dot_product", "scaled_dot_product_relu", "smrelu", "smscaled", "l2sm", "l2smrelu")
 PCM_GEO_MERGES = ("scaled_dot_product_geo", "scaled_dot_product_geo_relu", "att_is_all")     # models.py:287-299
+PCM_SUM_MERGES = ("cosine", "heu1", "heu2")                                                   # models.py:300-302, 307-320
 
 
 def pcm_geo_feature(p_enc_dim, spatial, dtype=torch.float32):
@@ -579,7 +580,7 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
     """PCM.forward (models.py:333-363) as dense tensor algebra.
     p: {"theta.weight", "theta.bias", "phi.*", "G.*", "r.*", "geo_theta.*", "geo_phi.*"} (absent = Identity,
     models.py:169-192).  cam [B, g_ch, D, H, W], f [B, in_ch, D, H, W] -> refined cam [B, g_ch, D, H, W]."""
-    if merge_type not in PCM_DOT_MERGES + PCM_GEO_MERGES:
+    if merge_type not in PCM_DOT_MERGES + PCM_GEO_MERGES + PCM_SUM_MERGES:
         raise NotImplementedError(merge_type)
     B, _, D, H, W = f.shape
     offs = pcm_offsets(k_size, connectivity, self_loop)
@@ -592,7 +593,25 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
         return tp[..., R + o[0]:R + o[0] + D, R + o[1]:R + o[1] + H, R + o[2]:R + o[2] + W]
     valid = torch.cat([shifted(ones, o) for o in offs], dim=1)              # [1, E, D, H, W]
     deg = valid.sum(1, keepdim=True)
-    if merge_type in PCM_GEO_MERGES:                                        # models.py:287-299
+    if merge_type in PCM_SUM_MERGES:                                        # no softmax: f / (eps + f.sum over the edges)
+        if merge_type == "cosine":
+            v = torch.stack([F.cosine_similarity(th, shifted(ph, o), dim=1) for o in offs], dim=1)
+            eps = 0.0
+        else:
+            dot = torch.stack([(th * shifted(ph, o)).sum(1) for o in offs], dim=1)
+            l1 = torch.stack([(th - shifted(ph, o)).abs().sum(1) for o in offs], dim=1)
+            v = dot / (1.0 + l1)
+            if merge_type == "heu1":
+                with torch.no_grad():
+                    mask = torch.ones_like(v)
+                    mask[v < 0.03] = 0.0
+                v = v * mask
+            else:
+                v = F.relu(v)
+            eps = 1e-7
+        v = v * valid
+        a = v / (eps + v.sum(1, keepdim=True))
+    elif merge_type in PCM_GEO_MERGES:                                      # models.py:287-299
         geo = pcm_geo_feature(p_enc_dim, (D, H, W), f.dtype).unsqueeze(0).expand(B, -1, D, H, W)
         gth, gph = _lin(p, "geo_theta", geo), _lin(p, "geo_phi", geo)
         if merge_type == "att_is_all":
@@ -653,7 +672,22 @@ def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
                     fm = fm / np.sqrt(fm.shape[-1])
                 if merge_type == "smscaled":
                     fm = fm / 0.01
-                f_sm = F.softmax(fm, dim=-1)
+                if merge_type in PCM_SUM_MERGES:                                          # merge_func, models.py:300-302, 307-320
+                    if merge_type == "cosine":
+                        fm = F.cosine_similarity(x_theta.transpose(-1, -2), x_phi, dim=-2).unsqueeze(-2)
+                        f_sm = fm / fm.sum(dim=-1, keepdim=True)
+                    else:
+                        fm = fm / (1.0 + torch.abs(x_theta.transpose(-1, -2) - x_phi).sum(dim=-2, keepdim=True))
+                        if merge_type == "heu1":
+                            with torch.no_grad():
+                                mask_f = torch.ones_like(fm)
+                                mask_f[fm < 0.03] = 0.0
+                            fm = fm * mask_f
+                        else:
+                            fm = F.relu(fm)
+                        f_sm = fm / (1e-7 + fm.sum(dim=-1, keepdim=True))
+                else:
+                    f_sm = F.softmax(fm, dim=-1)
                 x_g = lin("G", cam_agg).permute(1, 0, 2)                                  # [B, E, g_dim]
                 yv = torch.matmul(f_sm, x_g).squeeze(1)                                   # [B, g_dim]
                 out[:, :, z, y, x] = lin("r", yv)

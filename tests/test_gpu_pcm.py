@@ -104,6 +104,52 @@ def test_pcm_geo_merges_match_oracle(merge, shape, self_loop, iters, residual, c
         assert err <= TOL * max(scale, 1e-30), (k, err, scale)
 
 
+@pytest.mark.parametrize("merge", O.PCM_SUM_MERGES)
+@pytest.mark.parametrize("shape,self_loop,iters,residual,conn", [
+    ((5, 4, 7), False, 1, False, 2), ((1, 2, 3), True, 1, False, 2), ((6, 6, 6), False, 2, True, 2), ((4, 5, 6), True, 1, False, 3)])
+def test_pcm_sum_merges_match_oracle(merge, shape, self_loop, iters, residual, conn):
+    """cosine / heu1 / heu2 (models.py:300-302, 307-320): similarities normalised by their sum over a node's edges.
+    PARITY UNPINNED like all of PCM; against the oracle's fp64 restatement, values and every gradient.  Positive features
+    keep the sums away from zero (the reference divides by the bare sum for 'cosine'); heu1's 0.03 mask is exercised by the
+    scale of the features (about a third of the similarities fall below it)."""
+    import models
+    torch.manual_seed(9)
+    B, C, Fd, G, Gd = 2, 6, 5, 2, 3
+    m = models.PCM(shape, C, G, Fd, 0, Gd, iters, 3, merge_type=merge, self_loop=self_loop, connectivity=conn,
+                   residual=residual, p_enc_dim=0)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.startswith(("theta", "phi")):
+                p.abs_()
+                if merge == "heu1":
+                    p.mul_(0.12)        # similarities of about 0.01 ... 0.07: on both sides of the 0.03 mask
+    g = torch.Generator().manual_seed(10)
+    cam = torch.randn((B, G) + shape, generator=g)
+    f = torch.rand((B, C) + shape, generator=g)
+    gout = torch.randn((B, G) + shape, generator=g)
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    cam64, f64 = cam.double().requires_grad_(True), f.double().requires_grad_(True)
+    ref = O.pcm_forward(p64, cam64, f64, 3, conn, self_loop, merge, iters, residual)
+    (ref * gout.double()).sum().backward()
+    if merge == "heu1":                 # the mask really cuts: some, not all, same-node similarities lie below 0.03
+        with torch.no_grad():
+            th = torch.einsum("bc...,fc->bf...", f64, p64["theta.weight"]) + p64["theta.bias"].view(1, -1, 1, 1, 1)
+            ph = torch.einsum("bc...,fc->bf...", f64, p64["phi.weight"]) + p64["phi.bias"].view(1, -1, 1, 1, 1)
+            u = (th * ph).sum(1) / (1.0 + (th - ph).abs().sum(1))
+            assert 0.02 < (u < 0.03).double().mean().item() < 0.98
+    m = m.cuda()
+    camg, fg = cam.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
+    out = m(camg, fg)
+    (out * gout.cuda()).sum().backward()
+    assert rel(out, ref) <= TOL
+    assert rel(camg.grad, cam64.grad) <= TOL
+    assert rel(fg.grad, f64.grad) <= TOL
+    scale = max(v.grad.abs().max().item() for v in p64.values())
+    for k, p in m.named_parameters():
+        err = (p.grad.detach().cpu().double() - p64[k].grad).abs().max().item()
+        assert err <= TOL * max(scale, 1e-30), (k, err, scale)
+
+
 def _oracle_pcm(p, cam, f, conn, self_loop, merge, iters, residual):
     return O.pcm_forward(p, cam, f, 3, conn, self_loop, merge, iters, residual)
 
@@ -116,7 +162,7 @@ def test_pcm_offsets_match_oracle():
                 m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, k, merge_type="sm", self_loop=sl, connectivity=conn, p_enc_dim=0)
                 assert sorted(m.init_graph()) == sorted(tuple(int(v) for v in o) for o in O.pcm_offsets(k, conn, sl))
     with pytest.raises(NotImplementedError):
-        m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, 3, merge_type="cosine", p_enc_dim=0).cuda()
+        m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, 3, merge_type="l2", p_enc_dim=0).cuda()
         m(torch.zeros(1, 1, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
 
 

@@ -187,6 +187,20 @@ def test_pcm_dense_restatement_equals_literal_one(merge, self_loop):
     assert len(O.pcm_offsets(3, 2, False)) == 18 and len(O.pcm_offsets(3, 1, True)) == 7   # st_dram_ref_att: 18
 
 
+@pytest.mark.parametrize("merge", O.PCM_SUM_MERGES)
+def test_pcm_sum_merges_dense_restatement_equals_literal_one(merge):
+    """PARITY UNPINNED (DGL absent): cosine / heu1 / heu2 (models.py:300-302, 307-320) in the two restatements."""
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) + 0.1        # positive features: sums away from zero
+    p = {"theta.weight": r(4, 5), "theta.bias": r(4), "phi.weight": r(4, 5), "phi.bias": r(4),
+         "G.weight": r(3, 2), "G.bias": r(3), "r.weight": r(2, 3), "r.bias": r(2)}
+    for shape in [(4, 3, 5), (1, 2, 3)]:
+        cam, f = r(2, 2, *shape), r(2, 5, *shape)
+        a = O.pcm_forward(p, cam, f, 3, 2, False, merge)
+        b = O.pcm_forward_literal(p, cam, f, 3, 2, False, merge)
+        assert (a - b).abs().max().item() < 1e-10
+
+
 @pytest.mark.parametrize("merge", O.PCM_GEO_MERGES)
 @pytest.mark.parametrize("geo_f", [4, 0])
 def test_pcm_geo_dense_restatement_equals_literal_one(merge, geo_f):
