@@ -324,6 +324,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "per_gpu_voxels_per_s": value / world,
             "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "peak_hbm_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,      # what torch's allocator holds at the peak
+            "hbm_total_gb": torch.cuda.get_device_properties(dev).total_memory / 2 ** 30,
             # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 resp. 4/9 where the
             # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
             "network_executed_frac_of_fp32_peak": value / world * flops_per_voxel * exec_ratio / (PEAK_FP32_MFMA_TFLOPS * 1e12),
