@@ -732,8 +732,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 //   * the next chunk's global loads (the next item's first chunk at an item's end; issued right behind the barrier), its
 //     input transform and LDS stores ride in small pieces between the MFMAs of a chunk; filters go global -> LDS directly;
 //   * LDS operands arrive as ds_read_b64 (two k-steps per read: the channel-pair index kk is the fastest LDS axis) one
-//     iteration (4 MFMAs) ahead; the last iteration's MFMAs straddle the chunk's barrier (two before it, two behind
-//     the first operand reads of the next chunk), so the barrier and the LDS latency are covered by queued matrix work;
+//     iteration (4 MFMAs) ahead; the last iteration's MFMAs are issued behind the chunk's barrier, after the first
+//     operand reads of the next chunk, so that their LDS latency is covered by queued matrix work;
 //   * an item's epilogue runs inside the first iteration of the next item's first chunk.
 // Staging: wave w owns channel c0 + (w & 3) of the chunk; in waves 0-3 a lane = (y pair, x < 32) transforms one 4x4
 // patch (16 loads, 32 adds, 16 stores); waves 4-7 do the same for the two extra halo columns (4 lanes).
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         __syncthreads();
 
         int c_item = item_lo, c_c0 = 0, cur = 0;
-        bool pending = false;                       // the previous chunk's last two MFMAs are still to be issued
+        bool pending = false;                       // the previous chunk's last four MFMAs are still to be issued
         f32x2 av[2][2], bv[2][2];
     #ifdef DRAM_WZY_STAMPS
         unsigned long long st_acc[10] = {};
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 }
     #pragma unroll
                 for (int m = 0; m < 4; ++m) {                 // k = m / 2, h = m % 2
-                    if (go && (it > 0 || m >= 2)) {           // (the last iteration's first two were issued before the barrier)
+                    if (go) {
                         const int h = m & 1, k = m >> 1, xi = (2 * i0 + h) & 7;
                         acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
                     }
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (it == 0) {
-                    // (two MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
+                    // (the MFMAs of the previous chunk's last iteration are queued behind the barrier: they cover the latency
                     //  of the operand reads above; the next chunk's filter loads follow in iteration LD_W)
                     if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
     #ifdef DRAM_WZY_STAMPS
@@ -1200,14 +1200,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 }
     #endif
             }
-            // The last iteration's MFMAs straddle the barrier: two before it (matrix work queued while the waves gather), two
-            // after it (behind the next chunk's first operand reads).
-    #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int h = m & 1, k = m >> 1, xi = (2 * 11 + h) & 7;
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][h][k], bv[1][h][k], acc[xi], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // The last iteration's four MFMAs are issued behind the barrier, after the next chunk's first operand reads, whose
+            // latency they cover (measured, MFMAs before / behind the barrier: 0/4 is 1-2 % faster than 2/2, 4/0 1 % slower).
             pending = true;
             if (has_next) advance_staging();
     #ifdef DRAM_WZY_STAMPS
