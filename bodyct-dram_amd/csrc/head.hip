@@ -151,6 +151,69 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restr
     }
 }
 
+// The same for 16-byte aligned rows (S % 4 == 0, aligned pointers): a thread holds two float4 of dy and accumulates WG_CT
+// input channels in registers from 16-byte loads that are all in flight together, and the block reduces the WG_CT sums
+// once per channel tile (wave shuffles + one LDS exchange) -- 2 barriers per 16 channels instead of 2 per channel, which
+// is what held the scalar kernel at 3.6 TB/s.  Same partial layout, same fixed-order final sum.
+constexpr int WG_CT = 16;
+__global__ __launch_bounds__(256) void conv1x1_wgrad_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ part, int Cin, int Cout, int64_t S,
+                                                                int nblk, const float* __restrict__ coef, int relu) {
+    __shared__ float red[4][WG_CT + 1];
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blk * WG_VPB;
+    const int64_t e0 = base + 4 * tid, e1 = base + 1024 + 4 * tid;         // two float4 per thread
+    const bool ok0 = e0 < S, ok1 = e1 < S;
+    const float lo = (coef && relu) ? 0.f : -INFINITY;
+    for (int o = 0; o < Cout; ++o) {
+        const float* gp = dy + ((int64_t)n * Cout + o) * S;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g0 = ok0 ? *reinterpret_cast<const float4*>(gp + e0) : z4;
+        const float4 g1 = ok1 ? *reinterpret_cast<const float4*>(gp + e1) : z4;
+        float* prow = part + (((size_t)n * nblk + blk) * Cout + o) * (Cin + 1);
+        {
+            float gs = wave_sum(((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w)));
+            if (lane == 0) red[wv][WG_CT] = gs;
+        }
+        for (int c0 = 0; c0 < Cin; c0 += WG_CT) {
+            float acc[WG_CT];
+            float4 xa[WG_CT], xb[WG_CT];
+#pragma unroll
+            for (int k = 0; k < WG_CT; ++k) {
+                const int c = c0 + k < Cin ? c0 + k : Cin - 1;             // (tail channels: loaded, not stored)
+                const float* xp = x + ((int64_t)n * Cin + c) * S;
+                xa[k] = ok0 ? *reinterpret_cast<const float4*>(xp + e0) : z4;
+                xb[k] = ok1 ? *reinterpret_cast<const float4*>(xp + e1) : z4;
+            }
+#pragma unroll
+            for (int k = 0; k < WG_CT; ++k) {
+                float4 a = xa[k], b = xb[k];
+                if (coef) {   // the input is a RAW conv output: act(a*x + b) on load; out-of-range slots have g = 0
+                    const int c = c0 + k < Cin ? c0 + k : Cin - 1;
+                    const float ca = coef[2 * ((int64_t)n * Cin + c)], cb = coef[2 * ((int64_t)n * Cin + c) + 1];
+                    a.x = fmaxf(fmaf(ca, a.x, cb), lo); a.y = fmaxf(fmaf(ca, a.y, cb), lo);
+                    a.z = fmaxf(fmaf(ca, a.z, cb), lo); a.w = fmaxf(fmaf(ca, a.w, cb), lo);
+                    b.x = fmaxf(fmaf(ca, b.x, cb), lo); b.y = fmaxf(fmaf(ca, b.y, cb), lo);
+                    b.z = fmaxf(fmaf(ca, b.z, cb), lo); b.w = fmaxf(fmaf(ca, b.w, cb), lo);
+                }
+                float sacc = g0.x * a.x;
+                sacc = fmaf(g0.y, a.y, sacc); sacc = fmaf(g0.z, a.z, sacc); sacc = fmaf(g0.w, a.w, sacc);
+                sacc = fmaf(g1.x, b.x, sacc); sacc = fmaf(g1.y, b.y, sacc); sacc = fmaf(g1.z, b.z, sacc); sacc = fmaf(g1.w, b.w, sacc);
+                acc[k] = wave_sum(sacc);
+            }
+            __syncthreads();                                               // (the previous tile's sums have been read)
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < WG_CT; ++k) red[wv][k] = acc[k];
+            }
+            __syncthreads();
+            if (tid < WG_CT && c0 + tid < Cin) prow[c0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            if (c0 == 0 && tid == WG_CT) prow[Cin] = (red[0][WG_CT] + red[1][WG_CT]) + (red[2][WG_CT] + red[3][WG_CT]);
+        }
+        __syncthreads();
+    }
+}
+
 // out[j] = sum over `count` partial vectors of length L: one 256-thread block per j, fp64, fixed order
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int count, int L,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int Cin,
@@ -311,7 +374,11 @@ static int conv1x1_bwd_run(const float* dy, const float* x, const float* coef, i
         }
         const int nblk = (int)cdiv64(S, WG_VPB);
         float* part = (float*)ws;
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);
+        static_assert(WG_VPB == 2048, "conv1x1_wgrad_vec_kernel: two float4 per thread");
+        if ((S % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0 && getenv("DRAM_K1_WGRAD_SCALAR") == nullptr)
+            hipLaunchKernelGGL(conv1x1_wgrad_vec_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);
+        else
+            hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);
         const int L = Cout * (Cin + 1);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(L), dim3(256), 0, st, part, N * nblk, L, dw, dbias, Cin, Cout);
     }
