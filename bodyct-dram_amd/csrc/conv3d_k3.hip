@@ -891,6 +891,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // (measured: reading the two operand pairs of an iteration as four ds_read_b64 -- separate opaque bases, so that hipcc
         //  cannot merge them into ds_read2(st64)_b64 -- is 2-4 % SLOWER, although the merged form has half the LDS rate)
 
+#ifdef DRAM_WZY_STAMPS
+        unsigned long long ep_acc[6] = {};      // epilogue: transform, exchange write + barrier, read + combine + barrier, statistics, stores
+#define EP_STAMP(i_) { const unsigned long long tn_ = __builtin_readcyclecounter(); ep_acc[i_] += tn_ - ep_t; ep_t = tn_; }
+#else
+#define EP_STAMP(i_)
+#endif
         f32x16 acc[8];
     #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -1032,6 +1038,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             KArgs k = kargs();
             int n, x0, y0, z0, co0;
             decode(k, item, n, x0, y0, z0, co0);
+#ifdef DRAM_WZY_STAMPS
+            unsigned long long ep_t = __builtin_readcyclecounter();
+#endif
             // rows of A^T M (y part) for the wave's two xi_z: p[q][yy]
             float pq[2][2][16];
     #pragma unroll
@@ -1047,6 +1056,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             // z part: Y[0] = (p0 + p1) + p2, Y[1] = (p1 - p2) - p3.  The xh = 0 wave (p0, p1) finishes plane 0 and needs p2;
             // the xh = 1 wave (p2, p3) finishes plane 1 and needs p1.  Slot layout [wave][register][lane]: conflict-free.
+            EP_STAMP(0)
             float* mine = xch + wave * 32 * 64 + lane;
             const float* theirs = xch + (wave ^ 4) * 32 * 64 + lane;
     #pragma unroll
@@ -1054,6 +1064,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     #pragma unroll
                 for (int r = 0; r < 16; ++r) mine[(16 * yy + r) * 64] = xh == 0 ? pq[1][yy][r] : pq[0][yy][r];
             __syncthreads();
+            EP_STAMP(1)
             float yv[2][16];
     #pragma unroll
             for (int yy = 0; yy < 2; ++yy)
@@ -1064,6 +1075,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                                         : (got - pq[0][yy][r]) - pq[1][yy][r];      // (p1 - p2) - p3
                 }
             __syncthreads();           // every wave has read: the stage may be filled again
+            EP_STAMP(2)
             const int gx = x0 + j, gz = z0 + xh, gy = y0 + 2 * ty;
             const bool ok0 = gx < W && gz < D && gy < H;
             const bool ok1 = gx < W && gz < D && (gy + 1) < H;
@@ -1077,6 +1089,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                                   co0 + 32 * ct, kCout, k->nparts, box * 4 + 2 * ty + xh);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            EP_STAMP(3)
             // stores: the wave's 32 channels lie in ONE destination tensor (host: dst.C1 % 32 == 0) -> one descriptor over
             // them, lane offset = (its 4 kh channels, its voxel), the register's channel as a scalar offset
             const int cw = co0 + 32 * ct;
@@ -1109,6 +1122,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                                                               (int)((unsigned)((r & 3) + 8 * (r >> 2)) * cstride), 0);
                 }
             }
+            EP_STAMP(4)
+#ifdef DRAM_WZY_STAMPS
+            ep_acc[5] += 1;
+#endif
         };
 
         // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged,
@@ -1187,6 +1204,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     #ifdef DRAM_WZY_STAMPS
                     if (!c_valid && lane == 0)
                         for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[i], st_acc[i]);
+                    if (!c_valid && lane == 0)
+                        for (int i = 0; i < 6; ++i) atomicAdd(&g_wzy_stamps[10 + i], ep_acc[i]);
     #endif
                     if (!c_valid) return;
                     __builtin_amdgcn_sched_barrier(0);

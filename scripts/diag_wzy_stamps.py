@@ -36,3 +36,6 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
         tot = sum(out[q] for q in range(7)) / nch
         print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and chunk {tot:.0f}: " +
               ", ".join(f"{names[q]} {per[q]:.0f}" for q in range(7)), flush=True)
+        ne = max(out[15], 1)
+        en = ["A^T along y", "exchange write + barrier", "read + combine + barrier", "statistics", "stores"]
+        print(f"        epilogue per wave and item: " + ", ".join(f"{en[q]} {out[10 + q] / ne:.0f}" for q in range(5)), flush=True)
