@@ -69,9 +69,19 @@ def parse():
 
 
 def ensure_built():
-    if not os.path.exists(os.path.join(PKG, "libdram_hip.so")):
-        import __graft_entry__
-        __graft_entry__.build()
+    """`make` every time (a no-op when libdram_hip.so is newer than csrc/): a stale library must not be what is timed.
+    Without hipcc (a box that only received the prebuilt library) the existing library is used as it is."""
+    import shutil
+    import subprocess
+    lib = os.path.join(PKG, "libdram_hip.so")
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc) and shutil.which("make"):
+        rc = subprocess.call(["make", "-C", os.path.join(PKG, "csrc"), "-j", str(min(8, os.cpu_count() or 1)), "ARCH=gfx950",
+                              f"HIPCC={hipcc}"], stdout=subprocess.DEVNULL if os.path.exists(lib) else None)
+        if rc != 0 and not os.path.exists(lib):
+            sys.exit("bench.py: building libdram_hip.so failed")
+    elif not os.path.exists(lib):
+        sys.exit(f"bench.py: {lib} is missing and there is no hipcc to build it (no CPU fallback)")
 
 
 def host_cores():
@@ -158,7 +168,8 @@ def launch_ranks(n):
 
 def main():
     args = parse()
-    ensure_built()
+    if "WORLD_SIZE" not in os.environ or int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        ensure_built()          # (under a launcher only local rank 0 runs make; the others meet it at the first barrier)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
     import torch
@@ -192,6 +203,28 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         del warm
+    dist_info = None
+    if use_dist:
+        # What the process group really spans, gathered over the ranks (the line would otherwise prove n_gpus only as
+        # WORLD_SIZE): one record per rank = (device uuid / PCI bus id, device name, free bytes beside RCCL's buffers).
+        prop = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(prop, "uuid", "")) or f"{getattr(prop, 'pci_bus_id', '?')}:{getattr(prop, 'pci_device_id', '?')}"
+        if hasattr(prop, "pci_bus_id"):
+            ident += f"/bus{prop.pci_bus_id:02x}.{getattr(prop, 'pci_device_id', 0):02x}.{getattr(prop, 'pci_domain_id', 0)}"
+        free_b, _tot = torch.cuda.mem_get_info(dev)
+        mine = {"rank": rank, "local_rank": local, "device": ident, "name": prop.name, "free_gb_after_rccl_warmup": free_b / 2 ** 30}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        distinct = len({g["device"] for g in gathered})
+        dist_info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "distinct_devices": distinct,
+                     "devices": [g["device"] for g in gathered],
+                     "rccl_free_gb": min(g["free_gb_after_rccl_warmup"] for g in gathered)}
+        if dist.get_backend() == "nccl" and distinct != dist.get_world_size():
+            if rank == 0:
+                print(f"bench.py: {dist.get_world_size()} RCCL ranks on {distinct} distinct device(s): {dist_info['devices']}",
+                      file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     import models
     from dram_amd import functional as HF
@@ -243,11 +276,19 @@ def main():
     if use_timer:
         HF.TIMER = HF.KernelTimer()
     t0 = time.perf_counter()
+    losses = []
     for _ in range(args.steps):
-        trainer.step(batch, args.micro)
+        losses.append(trainer.step(batch, args.micro))        # (device scalars: no host synchronisation here)
     sync()
     elapsed = time.perf_counter() - t0
     timer, HF.TIMER = HF.TIMER, None
+    # ---- outside the timed region: what the timed steps computed (a wrong-but-fast step must not look like a result)
+    loss_hist = [(float(r), float(sg)) for r, sg in losses]
+    with torch.no_grad():
+        psum = sum(float(p.double().abs().sum()) for p in model.parameters())
+        gfinite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+        pfinite = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    finite = bool(gfinite and pfinite and all(x == x and abs(x) != float("inf") for pair in loss_hist for x in pair))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,7 +329,7 @@ def main():
                                 "F(2x2,3x3) over (z,y) 24 of the direct form's 54 multiply-adds per channel pair and "
                                 "voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = direct-conv FLOPs of SURVEY 8(d) / time"}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
-            # (collected on micro-batches of 16 x 128^3: only that workload has the same launches)
+            # (collected on the default workload, 64 x 128^3 as one batch: only that workload has the same launches)
             if os.path.exists(pmc) and (args.size, args.chunks, args.micro) == (128, 64, PMC_MICRO):
                 try:
                     t = json.load(open(pmc)).get(dom)
@@ -330,11 +371,18 @@ def main():
             # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
             "network_executed_frac_of_fp32_peak": value / world * flops_per_voxel * exec_ratio / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "network_algorithmic_equiv_tflops": value / world * flops_per_voxel / 1e12,
+            # the losses of the timed steps (rank 0's shard; reg summed over its chunks, seg weighted by its share of the
+            # global batch), a checksum of the parameters after the last step, and whether everything is finite
+            "loss": {"reg": [l[0] for l in loss_hist], "seg": [l[1] for l in loss_hist],
+                     "param_abs_sum_after": psum, "finite": finite},
+            "dist": dist_info,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if not finite:
+        sys.exit("bench.py: non-finite loss, gradient or parameter in the timed steps")
 
 
 if __name__ == "__main__":

@@ -35,6 +35,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <atomic>
 
 namespace dram {
 
@@ -2293,6 +2294,10 @@ static int pick_box(int D, int H, int W, const int (*boxes)[3], int nboxes, cons
     return best;
 }
 
+// box tables of the z-only Winograd kernel ((x, y) positions of a plane pair) and of the direct kernel
+static const int kFwdWzBoxes[4][2] = {{32, 4}, {16, 8}, {8, 16}, {10, 10}};
+static const int kFwdBoxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
+
 // The Winograd-z kernel serves every layer with enough input channels to amortise its filter tile; the first
 // layer (Cin = 1) and DRAM_CONV_DIRECT=1 (experiments, A/B tests) use the direct kernel.
 static bool use_wz(const ConvArgs& a) {
@@ -2334,7 +2339,7 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
     if (c.wz) {
         // position boxes: the padded plane area, weighted by the lanes a box leaves idle (10x10 uses 100 of 128: the
         // 20^3 and 10^3 levels of the reference's 80^3 chunks fit it exactly)
-        static const int boxes2[4][2] = {{32, 4}, {16, 8}, {8, 16}, {10, 10}};
+        const int (*boxes2)[2] = kFwdWzBoxes;
         int best = 0;
         double best_cost = -1.0;
         for (int i = 0; i < 4; ++i) {
@@ -2347,15 +2352,43 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
         c.box = best;
         c.nbx = cdiv(a.W, boxes2[best][0]); c.nby = cdiv(a.H, boxes2[best][1]); c.nbz = cdiv(a.D, 2);
     } else {
-        static const int boxes[3][3] = {{32, 4, 2}, {16, 4, 4}, {8, 8, 4}};
+        const int (*boxes)[3] = kFwdBoxes;
         c.box = pick_box(a.D, a.H, a.W, boxes, 3, "DRAM_FWD_BX");
         c.nbx = cdiv(a.W, boxes[c.box][0]); c.nby = cdiv(a.H, boxes[c.box][1]); c.nbz = cdiv(a.D, boxes[c.box][2]);
     }
     return c;
 }
 
+// What ran: launches per kernel family since the library was loaded (dram_conv3d_k3_launch_counts).  The tests of the
+// benchmarked shapes assert on these, so that "the (z,y) kernel was verified" means the (z,y) kernel was launched.
+static std::atomic<unsigned long long> g_launches[DRAM_K3_KINDS];
+
+// kind + instantiation name (as rocprofv3 prints it, without namespace and argument list) of the forward /
+// backward-data kernel that conv_fwd_dispatch launches for `a`
+static int fwd_kernel_id(const ConvArgs& a, const FwdChoice& c, char* name, size_t cap) {
+    const bool fused = a.coef1 || a.coef2 || a.stats;
+    const int cot = a.Cout <= 32 ? 1 : 2;
+    int kind;
+    char buf[96];
+    if (c.wzy) {
+        kind = DRAM_K3_FWD_WZY;
+        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wzy_kernel");
+    } else if (c.wz) {
+        kind = DRAM_K3_FWD_WZ;
+        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wz_kernel<%d, %d, %d, %s>", kFwdWzBoxes[c.box][0], kFwdWzBoxes[c.box][1], cot,
+                 fused ? "true" : "false");
+    } else {
+        kind = DRAM_K3_FWD_DIRECT;
+        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_kernel<%d, %d, %d, %d, %s>", kFwdBoxes[c.box][0], kFwdBoxes[c.box][1],
+                 kFwdBoxes[c.box][2], cot, fused ? "true" : "false");
+    }
+    if (name && cap) snprintf(name, cap, "%s", buf);
+    return kind;
+}
+
 static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     const FwdChoice c = fwd_choice(a);
+    g_launches[fwd_kernel_id(a, c, nullptr, 0)].fetch_add(1, std::memory_order_relaxed);
     if (a.stats) {
         DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * c.parts_per_box, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
                      "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * c.parts_per_box);
@@ -2479,6 +2512,39 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
     return check_launch("conv3d_k3_wgrad");
 }
 
+// The backward-weights kernel wgrad_run launches for a plan: kind + the instantiation's template arguments.
+struct WgradKernel {
+    int kind;               // DRAM_K3_WGRAD_*
+    int bx, by, bz, cos, cit;
+    bool lazy;
+};
+static WgradKernel wgrad_kernel(const WgradPlan& p, int C1, bool has_x2, int W, bool lazy) {
+    WgradKernel k;
+    k.bx = p.bx; k.by = p.by; k.bz = p.bz;
+    k.cos = p.variant == 1 ? 8 : 4;
+    k.cit = p.variant == 1 ? 1 : 2;
+    k.lazy = false;
+    if (p.wz) {
+        k.kind = lazy ? DRAM_K3_WGRAD_WZ_LAZY : DRAM_K3_WGRAD_WZ;
+        k.lazy = lazy;
+        return k;
+    }
+    // 16-byte staging needs full boxes along x and a channel tile that lies inside one source tensor
+    const int ci_b = 16 * k.cit;
+    const bool vec = (W % p.bx == 0) && (!has_x2 || C1 % ci_b == 0) && getenv("DRAM_WGRAD_NOVEC") == nullptr;
+    k.kind = vec ? DRAM_K3_WGRAD_VEC : DRAM_K3_WGRAD_DIRECT;
+    return k;
+}
+static void wgrad_kernel_name(const WgradKernel& k, char* name, size_t cap) {
+    if (!name || !cap) return;
+    if (k.kind == DRAM_K3_WGRAD_C1) snprintf(name, cap, "conv3d_k3_wgrad_c1_kernel");
+    else if (k.kind == DRAM_K3_WGRAD_WZ || k.kind == DRAM_K3_WGRAD_WZ_LAZY)
+        snprintf(name, cap, "conv3d_k3_wgrad_wz_kernel<%d, %d, %d, %d, %s>", k.bx, k.by, k.cos, k.cit, k.lazy ? "true" : "false");
+    else
+        snprintf(name, cap, "conv3d_k3_%s_kernel<%d, %d, %d, %d, %d>", k.kind == DRAM_K3_WGRAD_VEC ? "wgrad_vec" : "wgrad", k.bx, k.by,
+                 k.bz, k.cos, k.cit);
+}
+
 static int check_conv_shape(const char* who, int N, int Cin, int Cout, int D, int H, int W) {
     DRAM_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "%s: non-positive dimension", who);
     DRAM_REQUIRE((int64_t)D * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < 0x1fffffffLL,
@@ -2579,6 +2645,41 @@ extern "C" int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W
     return parts > 0x7fffffffLL ? 0 : (int)parts;
 }
 
+// Which kernel a forward / backward-data call of this shape launches (the same fwd_choice the launch uses).
+extern "C" int dram_conv3d_k3_fwd_choice(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
+                                         int dstW2, int fused, char* name, size_t cap) {
+    DRAM_REQUIRE(Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_fwd_choice: non-positive dimension");
+    DRAM_REQUIRE(dstC2 == 0 || dstC1 + dstC2 == Cout, "conv3d_k3_fwd_choice: the destination split does not add up to Cout");
+    ConvArgs a = {};
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.dst.C1 = dstC2 > 0 ? dstC1 : Cout;
+    a.dst.C2 = dstC2 > 0 ? dstC2 : 0;
+    a.dst.D2 = dstC2 > 0 ? dstD2 : 1; a.dst.H2 = dstC2 > 0 ? dstH2 : 1; a.dst.W2 = dstC2 > 0 ? dstW2 : 1;
+    static const float dummy = 0.f;
+    if (fused) a.stats = const_cast<float*>(&dummy);          // (only tested for null-ness by fwd_kernel_id)
+    return fwd_kernel_id(a, fwd_choice(a), name, cap);
+}
+
+// Which kernel a backward-weights call of this shape launches (the same wgrad_plan / wgrad_kernel the launch uses).
+extern "C" int dram_conv3d_k3_wgrad_choice(int N, int C1, int C2, int Cout, int D, int H, int W, int lazy, char* name, size_t cap) {
+    DRAM_REQUIRE(N > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_wgrad_choice: bad dimension");
+    WgradKernel k = {};
+    if (C1 + C2 == 1) {
+        k.kind = DRAM_K3_WGRAD_C1;
+    } else {
+        const WgradPlan p = wgrad_plan(N, C1 + C2, Cout, D, H, W, C2 > 0 ? C1 : 0);
+        k = wgrad_kernel(p, C1, C2 > 0, W, lazy != 0 && p.wz);
+    }
+    wgrad_kernel_name(k, name, cap);
+    return k.kind;
+}
+
+extern "C" int dram_conv3d_k3_launch_counts(unsigned long long* counts, int n) {
+    DRAM_REQUIRE(counts && n > 0, "conv3d_k3_launch_counts: null pointer");
+    for (int i = 0; i < n; ++i) counts[i] = i < DRAM_K3_KINDS ? g_launches[i].load(std::memory_order_relaxed) : 0ull;
+    return DRAM_OK;
+}
+
 // Fused forward: each source may be the RAW output of the previous conv with its norm (+ReLU) applied on load
 // (coefK = per-row {a, b}, null = plain tensor), and the statistics of the output are accumulated in the epilogue.
 extern "C" int dram_conv3d_k3_fwd_fused(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2,
@@ -2668,6 +2769,7 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
             return DRAM_EWS;
         }
         hipStream_t st1 = (hipStream_t)stream;
+        g_launches[DRAM_K3_WGRAD_C1].fetch_add(1, std::memory_order_relaxed);
         hipLaunchKernelGGL(conv3d_k3_wgrad_c1_kernel, dim3(blocks, cdiv(Cout, 32)), dim3(256), 0, st1, c);
         const int64_t E1 = (int64_t)Cout * 27;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E1, 256)), dim3(256), 0, st1, c.slabs, dw, E1, 4 * blocks);
@@ -2688,9 +2790,9 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
     a.nbx = p.nbx; a.nby = p.nby; a.nbz = p.nbz; a.nboxes = p.nboxes;
     a.split = p.split; a.ci_tiles = p.ci_tiles; a.co_tiles = p.co_tiles;
     hipStream_t st = (hipStream_t)stream;
-    // 16-byte staging needs full boxes along x and a channel tile that lies inside one source tensor
-    const int ci_b = p.variant == 1 ? 16 : 32;
-    const bool vec = (W % p.bx == 0) && (x2 == nullptr || C1 % ci_b == 0) && getenv("DRAM_WGRAD_NOVEC") == nullptr;
+    const WgradKernel wk = wgrad_kernel(p, C1, x2 != nullptr, W, a.coef1 || a.coef2);
+    g_launches[wk.kind].fetch_add(1, std::memory_order_relaxed);
+    const bool vec = wk.kind == DRAM_K3_WGRAD_VEC;
     if (p.wz) {
         if (p.variant == 1)
             rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : p.bx == 8 ? launch_wgrad_wz<8, 4, 8, 1>(a, st) : launch_wgrad_wz<4, 8, 8, 1>(a, st);

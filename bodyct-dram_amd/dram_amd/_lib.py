@@ -87,6 +87,9 @@ SIGNATURES = {
     "dram_conv3d_k3_fwd_fused": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, P, I, I, I, I, I, I, P]),
     "dram_conv3d_k3_wgrad_lazy_ok": (I, [I, I, I, I, I, I, I]),
     "dram_conv3d_k3_wgrad_fused": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, Z, I, I, I, I, I, P]),
+    "dram_conv3d_k3_fwd_choice": (I, [I, I, I, I, I, I, I, I, I, I, I, c_char_p, Z]),
+    "dram_conv3d_k3_wgrad_choice": (I, [I, I, I, I, I, I, I, I, c_char_p, Z]),
+    "dram_conv3d_k3_launch_counts": (I, [P, I]),
     "dram_norm_parts_ws_bytes": (Z, [I, I, I]),
     "dram_norm_finalize_parts": (I, [P, I, P, P, P, P, P, P, P, F, F, I, I, I, I, L, P, Z, P]),
     "dram_bn_eval_coef": (I, [P, P, P, P, P, P, P, F, I, I, P]),

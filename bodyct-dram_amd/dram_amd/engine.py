@@ -79,8 +79,9 @@ class Upsampled:
     def __init__(self, src, size):
         self.src, self.size, self.kept = src, tuple(int(v) for v in size), None
 
-    def produce(self, lo=0, hi=None, may_keep=False):
-        """The upsampled tensor of samples [lo, hi) (default: all)."""
+    def produce(self, lo=0, hi=None, keep_below=0):
+        """The upsampled tensor of samples [lo, hi) (default: all); the whole tensor is kept for backward when it is
+        smaller than `keep_below` bytes."""
         N, C, D, H, W = self.src.raw.shape
         hi = N if hi is None else hi
         if self.kept is not None:
@@ -89,8 +90,7 @@ class Upsampled:
         y = torch.empty((n, C) + self.size, dtype=torch.float32, device=self.src.raw.device)
         call("dram_upsample_trilinear_ac_fwd_lazy", _p(self.src.raw[lo:hi]), _p(_rows(self.src.coef, lo, hi, C)),
              int(self.src.relu), _p(y), n, C, D, H, W, *self.size, _stream())
-        if may_keep and (lo, hi) == (0, N) and \
-                y.numel() * 4 < KEEP_UPSAMPLED_BELOW * torch.cuda.get_device_properties(y.device).total_memory:
+        if (lo, hi) == (0, N) and y.numel() * 4 < keep_below:
             self.kept = y
         return y
 
@@ -140,7 +140,7 @@ def parameters_of(model):
 class _Stage:
     """What backward needs of one conv -> norm -> ReLU stage."""
     __slots__ = ("conv", "norm", "inp", "skip", "geom", "y", "coef", "mean", "rstd", "kind", "groups", "batch_stats",
-                 "out", "need_input_grad")
+                 "out", "need_input_grad", "ranges")
 
 
 def _norm_plan(norm, training):
@@ -167,18 +167,18 @@ def _lazy_slice(lz, lo, hi):
     return Lazy(lz.raw[lo:hi], _rows(lz.coef, lo, hi, lz.raw.shape[1]), lz.relu)
 
 
-def _slices(inp, N):
-    """Sample ranges in which a stage with input `inp` is executed."""
-    if not isinstance(inp, Upsampled) or inp.kept is not None:
+def _slices(inp, N, budget):
+    """Sample ranges in which a stage with input `inp` is executed: slices whose upsampled tensor stays below `budget`
+    bytes.  Decided ONCE, in forward; backward walks the ranges the tape recorded."""
+    if not isinstance(inp, Upsampled):
         return [(0, N)]
     C = inp.src.raw.shape[1]
     per_sample = 4 * C * inp.size[0] * inp.size[1] * inp.size[2]
-    budget = SLICE_UPSAMPLED_ABOVE * torch.cuda.get_device_properties(inp.src.raw.device).total_memory
     n = max(1, min(N, int(budget // per_sample)))
     return [(lo, min(N, lo + n)) for lo in range(0, N, n)]
 
 
-def _conv_stage(conv, norm, inp, skip, training, record):
+def _conv_stage(conv, norm, inp, skip, training, record, plan):
     """y = conv(inp ++ crop(skip)) with the moments of y from the epilogue -> Lazy(y, coef, relu).  `inp` is a Lazy or
     an Upsampled recipe (then produced here -- whole, or slice by slice -- used, and dropped unless it is small)."""
     up = isinstance(inp, Upsampled)
@@ -209,11 +209,12 @@ def _conv_stage(conv, norm, inp, skip, training, record):
     name = HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True)
     nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W) if use_batch else 0
     parts = torch.empty(N * Co * nparts * 3, dtype=torch.float32, device=dev) if use_batch else None
-    ranges = _slices(inp, N) if up else [(0, N)]
+    ranges = _slices(inp, N, plan.slice_up) if up else [(0, N)]
+    plan.sliced_stages += len(ranges) > 1
     for lo, hi in ranges:
         n = hi - lo
         if up:
-            x1 = Lazy(inp.produce(lo, hi, may_keep=record is not None and len(ranges) == 1))
+            x1 = Lazy(inp.produce(lo, hi, keep_below=plan.keep_up if record is not None and len(ranges) == 1 else 0))
         else:
             x1 = inp if (lo, hi) == (0, N) else _lazy_slice(inp, lo, hi)
         sk = None if skip is None else (skip if (lo, hi) == (0, N) else _lazy_slice(skip, lo, hi))
@@ -231,7 +232,7 @@ def _conv_stage(conv, norm, inp, skip, training, record):
     else:   # eval-mode BatchNorm: coefficients from the running statistics
         call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
     out = Lazy(y, coef, relu=True)
-    if record is not None and y.numel() * 4 < MATERIALISE_BELOW * torch.cuda.get_device_properties(dev).total_memory:
+    if record is not None and y.numel() * 4 < plan.materialise:
         out = Lazy(out.materialise())        # (inference keeps everything lazy: nothing is kept there anyway)
     if record is not None:
         s = _Stage()
@@ -239,15 +240,16 @@ def _conv_stage(conv, norm, inp, skip, training, record):
         s.geom = (C1, C2, D2, H2, W2, oz, oy, ox)
         s.y, s.coef, s.mean, s.rstd = y, coef, mean, rstd
         s.kind, s.groups, s.batch_stats, s.out = kind, groups, bool(use_batch), out
+        s.ranges = ranges
         record.append(("conv", s))
     return out
 
 
-def _conv_stack(conv_blocks, inp, skip, training, record):
+def _conv_stack(conv_blocks, inp, skip, training, record, plan):
     cur = inp
     for j, seq in enumerate(conv_blocks):
         conv, norm, _ = _stage_modules(seq)
-        cur = _conv_stage(conv, norm, cur, skip if j == 0 else None, training, record)
+        cur = _conv_stage(conv, norm, cur, skip if j == 0 else None, training, record, plan)
     return cur
 
 
@@ -292,29 +294,54 @@ def _raw_output_bytes(model, x):
     return total * vox
 
 
-def _apply_memory_mode(model, x, training):
-    global MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE
+class _Plan:
+    """The memory decisions of ONE forward call, in bytes; kept on its tape, so that the matching backward -- whatever ran in
+    between (an eval pass, another batch size, another model, another thread) -- releases and slices what forward planned."""
+    __slots__ = ("mode", "materialise", "keep_up", "slice_up", "sliced_stages")
+
+    def __init__(self, mode, fracs, cap):
+        self.mode = mode
+        self.materialise, self.keep_up, self.slice_up = (f * cap for f in fracs)
+        self.sliced_stages = 0          # (diagnostics) stages that ran in more than one slice of samples
+
+
+def _memory_plan(model, x, training):
+    cap = torch.cuda.get_device_properties(x.device).total_memory
     mode = MEMORY_MODE
     if mode == "auto":
-        cap = torch.cuda.get_device_properties(x.device).total_memory
         # the written activations and kept upsampled tensors add ~1.2x the raw outputs on top of them
         mode = "tight" if training and 2.2 * _raw_output_bytes(model, x) > 0.62 * cap else "speed"
-    MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE = _TIGHT if mode == "tight" else _SPEED
-    return mode
+    if mode == "tight":
+        fracs = _TIGHT
+    elif mode == "speed":
+        fracs = _SPEED
+    else:       # "manual": the three module-level thresholds as the caller set them
+        fracs = (MATERIALISE_BELOW, KEEP_UPSAMPLED_BELOW, SLICE_UPSAMPLED_ABOVE)
+    return _Plan(mode, fracs, cap)
+
+
+LAST_PLAN = None        # (diagnostics only, never read by the engine) the plan of the most recent forward call
+MAX_PLANES = 65535      # (n, c) planes per launch of the row / plane kernels (norm, pool, resize: planes ride on grid.y)
 
 
 def forward(model, x, record):
     """DC3D.forward (models.py:120-147) on lazy tensors.  `record`: list that receives the tape for backward, or None
     (inference).  Returns the dense output [N, out_ch, D, H, W]."""
+    global LAST_PLAN
     training = model.training
-    if MEMORY_MODE in ("auto", "speed", "tight"):        # ("manual": the three thresholds as set by the caller)
-        _apply_memory_mode(model, x, record is not None)
+    plan = LAST_PLAN = _memory_plan(model, x, record is not None)
     L = model.n_layers
     x = HF._chk(x, "DC3D input", 5)
+    widest = max(seq[0].out_channels for blk in list(model.ds_modules) + [model.bg] + list(model.us_modules or [])
+                 for seq in blk.conv_blocks)
+    if x.shape[0] * widest > MAX_PLANES:
+        raise ValueError(f"DC3D: {x.shape[0]} chunks x {widest} channels = {x.shape[0] * widest} (n, c) planes exceed the "
+                         f"{MAX_PLANES} a kernel launch addresses: run micro-batches of at most {MAX_PLANES // widest} chunks "
+                         f"(DataParallelTrainer.step(batch, micro_batch=...))")
     grad_flows = record is not None          # the reference re-runs a checkpointed block in backward only then
     cur = Lazy(x)
     if record is not None:
-        record.append(("input", cur))
+        record.append(("input", cur, plan))
     skips = []
 
     def run_block(flag, block, fn):
@@ -331,10 +358,10 @@ def forward(model, x, record):
                 m.stat_updates = 1
 
     for i, ds in enumerate(model.ds_modules):
-        feat = run_block(model.checkpoint_layers[i], ds, lambda: _conv_stack(ds.conv_blocks, cur, None, training, record))
+        feat = run_block(model.checkpoint_layers[i], ds, lambda: _conv_stack(ds.conv_blocks, cur, None, training, record, plan))
         skips.append(feat)
         cur = _pool(feat, record)
-    cur = run_block(model.checkpoint_layers[L], model.bg, lambda: _conv_stack(model.bg.conv_blocks, cur, None, training, record))
+    cur = run_block(model.checkpoint_layers[L], model.bg, lambda: _conv_stack(model.bg.conv_blocks, cur, None, training, record, plan))
     if model.us_modules is not None:
         for i, (us, skip) in enumerate(zip(model.us_modules, reversed(skips))):
             if model.stacking == i:
@@ -348,7 +375,7 @@ def forward(model, x, record):
             if record is not None:
                 record.append(("up", cur, size))
             # NB: the flag index is n_layers + idx, not n_layers + 1 + idx (models.py:140)
-            cur = run_block(model.checkpoint_layers[L + i], us, lambda: _conv_stack(us.conv_blocks, up, skip, training, record))
+            cur = run_block(model.checkpoint_layers[L + i], us, lambda: _conv_stack(us.conv_blocks, up, skip, training, record, plan))
     top = model.top_layer
     N, C, D, H, W = cur.raw.shape
     Co = top.weight.shape[0]
@@ -434,7 +461,7 @@ def backward(model, record, gout, need_dx):
             up = isinstance(inp, Upsampled)
             is_root = (not up) and inp is root
             need_dgrad = skip is not None or not is_root or need_dx
-            ranges = _slices(inp, N) if up else [(0, N)]
+            ranges = s.ranges                  # as forward ran the stage (decided once, kept on the tape)
             whole = len(ranges) == 1
             lazy_ok = bool(_lib.lib.dram_conv3d_k3_wgrad_lazy_ok(N, C1, C2, Co, D, H, W)) and not _os.environ.get("DRAM_ENGINE_NO_LAZY_WGRAD")
             dw = None
@@ -463,7 +490,7 @@ def backward(model, record, gout, need_dx):
                     sk = Lazy(sk.materialise()) if sk is not None else None
                 dws = torch.empty_like(w)
                 wsb = _ws(_lib.lib.dram_conv3d_k3_wgrad_ws_bytes(n, Ci, Co, D, H, W), g.device)
-                name = HF.conv_wgrad_kernel_name((D, H, W), Co, Ci if skip is None else None,
+                name = HF.conv_wgrad_kernel_name(n, (D, H, W), Co, C1, C2,
                                                  lazy=(x1.coef is not None or (sk is not None and sk.coef is not None)))
                 HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                                "dram_conv3d_k3_wgrad_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
@@ -475,7 +502,8 @@ def backward(model, record, gout, need_dx):
                 # backward-data: gradient w.r.t. the activated input(s)
                 if need_dgrad:
                     dx1 = torch.empty((n, C1, D, H, W), dtype=torch.float32, device=g.device)
-                    HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+                    HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if dx2 is not None else None),
+                                   54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                                    "dram_conv3d_k3_fwd_ex", _p(gs), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                                    _p(dx1), C1, _p(dx2[lo:hi]) if dx2 is not None else None, C2, D2, H2, W2, oz, oy, ox,
                                    n, D, H, W, st)

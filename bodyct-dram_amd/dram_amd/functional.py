@@ -56,39 +56,39 @@ def _timed_call(key, flops, nbytes, name, *args):
     TIMER.records.append((key, flops, nbytes, e0, e1))
 
 
-def _pick_box(dhw, boxes):
-    """csrc/conv3d_k3.hip pick_box: the box that pads the volume least, ties to the first listed."""
-    D, H, W = dhw
-    vol = lambda b: -(-W // b[0]) * b[0] * (-(-H // b[1]) * b[1]) * (-(-D // b[2]) * b[2])
-    return min(boxes, key=vol)
+# kernel families of the 3x3x3 conv (include/dram_hip.h DRAM_K3_*)
+K3_FWD_DIRECT, K3_FWD_WZ, K3_FWD_WZY, K3_WGRAD_DIRECT, K3_WGRAD_VEC, K3_WGRAD_WZ, K3_WGRAD_WZ_LAZY, K3_WGRAD_C1, \
+    K3_FWD_C1, K3_WGRAD_WZY, K3_KINDS = range(11)
 
 
-def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False):
-    """Name of the forward / backward-data kernel instantiation the library picks (csrc/conv3d_k3.hip
-    fwd_choice), as rocprofv3 prints it.  `fused`: the variant with lazy operands / the statistics epilogue."""
-    cot = 1 if Cout <= 32 else 2
-    flag = "true" if fused else "false"
-    if Cin >= 8 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):
-        padded = -(-dhw[2] // 32) * 32 * -(-dhw[1] // 4) * 4 * -(-dhw[0] // 2) * 2
-        if Cout % 64 == 0 and padded <= 1.2 * dhw[0] * dhw[1] * dhw[2] and not os.environ.get("DRAM_CONV_NO_WZY"):
-            return "conv3d_k3_fwd_wzy_kernel"                   # Winograd over (z, y): use_wzy(); one instantiation
-        box = min([(32, 4), (16, 8), (8, 16), (10, 10)], key=lambda b: -(-dhw[2] // b[0]) * -(-dhw[1] // b[1]))
-        return f"conv3d_k3_fwd_wz_kernel<{box[0]}, {box[1]}, {cot}, {flag}>"
-    box = _pick_box(dhw, [(32, 4, 2), (16, 4, 4), (8, 8, 4)])
-    return f"conv3d_k3_fwd_kernel<{box[0]}, {box[1]}, {box[2]}, {cot}, {flag}>"
+def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False, dst_split=None):
+    """Name of the forward / backward-data kernel instantiation the library launches for this shape, as rocprofv3
+    prints it -- asked of the library itself (dram_conv3d_k3_fwd_choice: the same fwd_choice the launch goes through).
+    `fused`: the variant with lazy operands / the statistics epilogue; `dst_split` = (C1, C2, D2, H2, W2) when the
+    output is written to two tensors (backward-data of a conv whose input was a virtual concat)."""
+    c1, c2, d2, h2, w2 = dst_split if dst_split is not None else (Cout, 0, 0, 0, 0)
+    buf = ctypes.create_string_buffer(96)
+    kind = _lib.lib.dram_conv3d_k3_fwd_choice(Cin, Cout, dhw[0], dhw[1], dhw[2], c1, c2, d2, h2, w2, int(bool(fused)), buf, len(buf))
+    if kind < 0:
+        raise _lib.DramHipError(f"dram_conv3d_k3_fwd_choice: {_lib.lib.dram_last_error().decode()}")
+    return buf.value.decode()
 
 
-def conv_wgrad_kernel_name(dhw, Cout, Cin=None, lazy=False):
-    if Cin == 1:
-        return "conv3d_k3_wgrad_c1_kernel"
-    tile = '8, 1' if Cout > 64 else '4, 2'
-    if dhw[2] % 4 == 0 and dhw[0] >= 2 and not os.environ.get("DRAM_CONV_DIRECT"):   # csrc/conv3d_k3.hip wgrad_plan
-        bx = 16 if dhw[2] % 16 == 0 else (8 if dhw[2] % 8 == 0 else 4)
-        # (the 64 co x 32 ci tile whatever Cout; a concat boundary that is a multiple of 16 only gets '8, 1': label only)
-        return f"conv3d_k3_wgrad_wz_kernel<{bx}, {32 // bx}, 4, 2, {'true' if lazy else 'false'}>"
-    box = _pick_box(dhw, [(16, 2, 2), (32, 2, 1), (8, 4, 2)])
-    kind = "wgrad_vec" if dhw[2] % box[0] == 0 else "wgrad"       # 16-byte staging needs full boxes along x
-    return f"conv3d_k3_{kind}_kernel<{box[0]}, {box[1]}, {box[2]}, {tile}>"
+def conv_wgrad_kernel_name(N, dhw, Cout, C1, C2=0, lazy=False):
+    """Name of the backward-weights kernel instantiation for x = x1[N, C1] ++ crop(x2[N, C2]) (dram_conv3d_k3_wgrad_choice:
+    the same wgrad_plan the launch goes through)."""
+    buf = ctypes.create_string_buffer(96)
+    kind = _lib.lib.dram_conv3d_k3_wgrad_choice(N, C1, C2, Cout, dhw[0], dhw[1], dhw[2], int(bool(lazy)), buf, len(buf))
+    if kind < 0:
+        raise _lib.DramHipError(f"dram_conv3d_k3_wgrad_choice: {_lib.lib.dram_last_error().decode()}")
+    return buf.value.decode()
+
+
+def conv_launch_counts():
+    """Launches per 3x3x3 conv kernel family (index = K3_*) since the library was loaded."""
+    arr = (ctypes.c_ulonglong * K3_KINDS)()
+    call("dram_conv3d_k3_launch_counts", ctypes.cast(arr, ctypes.c_void_p), K3_KINDS)
+    return list(arr)
 
 
 def _p(t):
@@ -181,7 +181,8 @@ class Conv3dK3Fn(Function):
                 full = (D2, H2, W2) == (D, H, W)
                 dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
             vox = N * D * H * W
-            _timed_call(conv_fwd_kernel_name((D, H, W), Ci, Co), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if x2 is not None else None),
+                        54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                         _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
             if not need1:
@@ -193,7 +194,7 @@ class Conv3dK3Fn(Function):
             nbytes = _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)
             ws = _ws(nbytes, dy.device)
             vox = N * D * H * W
-            _timed_call(conv_wgrad_kernel_name((D, H, W), Co, Ci if x2 is None else None), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_wgrad_kernel_name(N, (D, H, W), Co, C1, C2), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_wgrad_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(dy), _p(dw),
                         _p(ws), ws.numel(), N, Co, D, H, W, st)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -780,8 +781,8 @@ PCM_SUM_MERGES = {"cosine": 0, "heu1": 1, "heu2": 2}
 
 class PcmAttentionSumFn(Function):
     """attn[b,e,i] = v_e / (eps + sum_k v_k) over node i's in-grid neighbours with v = the cosine similarity of
-    (theta_i, phi_(i+o_e)) / the heuristic similarity theta.phi / (1 + |theta - phi|_1), masked below 0.03 (heu1, the mask
-    carries no gradient) or rectified (heu2)."""
+    (theta_i, phi_(i+o_e)) / the heuristic similarity theta.phi / (1 + |theta - phi|_1), masked below 0.03 (heu1: formed
+    under no_grad in the reference, so that attention carries no gradient at all) or rectified (heu2)."""
 
     @staticmethod
     def forward(ctx, theta, phi, offsets, mode):
@@ -801,6 +802,10 @@ class PcmAttentionSumFn(Function):
     def backward(ctx, dattn):
         theta, phi, attn = ctx.saved_tensors
         offsets, mode = ctx.cfg
+        if mode == PCM_SUM_MERGES["heu1"]:
+            # reference models.py:311-314: `f = f * mask_f` sits inside `with torch.no_grad():`, so the masked similarities --
+            # and the whole heu1 attention -- are constants of the graph: no gradient reaches theta or phi
+            return None, None, None, None
         dattn = _chk(dattn, "pcm attention grad_output", 5)
         B, Fd, D, H, W = theta.shape
         arr, E = _offsets_arg(offsets)
@@ -860,11 +865,21 @@ def pcm_attention(theta, phi, offsets, merge_type, geo_theta=None, geo_phi=None)
         return PcmAttentionFn.apply(th, ph, offsets, PCM_RELU, 1, theta.shape[1])     # relu(theta.phi) + geo_theta.geo_phi
     if merge_type in PCM_SUM_MERGES:
         return PcmAttentionSumFn.apply(theta, phi, offsets, PCM_SUM_MERGES[merge_type])
+    if merge_type == "l2":
+        # models.py:262-264: f = exp(-5 (theta - phi)^2), f / f.sum over the edges.  The reference subtracts [.., 1, f_dim] and
+        # [.., f_dim, edges] tensors and later reshapes the aggregate to one row per node (models.py:396): both only work for
+        # f_dim == 1.  There it is a softmax over the edges of -5 (theta - phi_e)^2 = -5 theta^2 + 10 theta phi_e - 5 phi_e^2,
+        # whose first term is common to a node's edges and cancels: the 'sm' kernel on the feature pairs
+        # (10 theta, -5) . (phi, phi^2).
+        if theta.shape[1] != 1:
+            raise ValueError(f"PCM merge_type 'l2' is only defined for f_dim == 1 (got {theta.shape[1]}): the reference "
+                             f"broadcasts [.., 1, f_dim] against [.., f_dim, edges] (models.py:263)")
+        th2 = torch.cat([10.0 * theta, torch.full_like(theta, -5.0)], 1)
+        ph2 = torch.cat([phi, phi * phi], 1)
+        return PcmAttentionFn.apply(th2, ph2, offsets, 0, 0)
     if merge_type not in PCM_MERGE_MODES:
-        # ('l2', models.py:260-262, subtracts [.., 1, f_dim] and [.., f_dim, edges] tensors: it only broadcasts when f_dim equals
-        #  the number of edges, and then weights every edge per feature -- not provided)
         raise NotImplementedError(f"PCM merge_type {merge_type!r}: the dot-product family {sorted(PCM_MERGE_MODES)}, the "
-                                  f"geo family {list(PCM_GEO_MERGES)} and {sorted(PCM_SUM_MERGES)} are implemented on the device")
+                                  f"geo family {list(PCM_GEO_MERGES)}, {sorted(PCM_SUM_MERGES)} and 'l2' are implemented on the device")
     flags, scale_mode = PCM_MERGE_MODES[merge_type]
     return PcmAttentionFn.apply(theta, phi, offsets, flags, scale_mode)
 

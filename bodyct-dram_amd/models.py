@@ -231,8 +231,9 @@ class PCM(nn.Module):
     Implemented merge types: the dot-product family `dram_amd.functional.PCM_MERGE_MODES`
     (incl. the shipped 'scaled_dot_product_relu'), the geo family `PCM_GEO_MERGES` (an appearance term
     plus a term over sin/cos positional encodings, `build_geo_feature`) and the sum-normalised
-    `PCM_SUM_MERGES` (cosine, heu1, heu2); 'l2' (which only broadcasts when f_dim equals the number of
-    edges) raises NotImplementedError at call time, like the reference does for unknown names."""
+    `PCM_SUM_MERGES` (cosine, heu1, heu2) and 'l2' for f_dim == 1 (the one width for which the reference's broadcast
+    of [.., 1, f_dim] against [.., f_dim, edges] and the reshape at models.py:396 are defined; other widths raise
+    ValueError).  Unknown names raise NotImplementedError at call time, like the reference."""
 
     def __init__(self, pool_size, in_ch, g_ch, f_dim, geo_f_dim, g_dim, non_local_iter, k_size,
                  merge_type='l2', self_loop=True, connectivity=2, residual=False, p_enc_dim=32):

@@ -345,6 +345,33 @@ int dram_conv3d_k3_wgrad_fused(const float* x1, int C1, const float* coef1, int 
                                const float* dy, float* dw, void* ws, size_t ws_bytes, int N, int Cout, int D,
                                int H, int W, void* stream);
 
+/* ---- which 3x3x3 conv kernel the library launches (the reference leaves this choice to cuDNN's heuristics behind
+ * nn.Conv3d, parts.py:95..185; here it is a pure function of the shape, exposed so that benchmarks attribute time to
+ * the right kernel and tests assert that the kernel they mean to verify is the one that ran) ----
+ * Kernel families; the *_choice queries return one of these and write the instantiation's name as rocprofv3 prints
+ * it (without namespace and argument list, e.g. "conv3d_k3_wgrad_wz_kernel<16, 2, 4, 2, true>") to name[cap]. */
+#define DRAM_K3_FWD_DIRECT 0    /* conv3d_k3_fwd_kernel: direct 27-tap form (first layer, DRAM_CONV_DIRECT=1) */
+#define DRAM_K3_FWD_WZ 1        /* conv3d_k3_fwd_wz_kernel: Winograd F(2,3) along z */
+#define DRAM_K3_FWD_WZY 2       /* conv3d_k3_fwd_wzy_kernel: Winograd F(2x2,3x3) over (z,y) */
+#define DRAM_K3_WGRAD_DIRECT 3  /* conv3d_k3_wgrad_kernel */
+#define DRAM_K3_WGRAD_VEC 4     /* conv3d_k3_wgrad_vec_kernel: direct form, 16-byte staging */
+#define DRAM_K3_WGRAD_WZ 5      /* conv3d_k3_wgrad_wz_kernel<.., false>: transposed F(2,3) along z, plain x operand */
+#define DRAM_K3_WGRAD_WZ_LAZY 6 /* conv3d_k3_wgrad_wz_kernel<.., true>: x normalised + rectified on load */
+#define DRAM_K3_WGRAD_C1 7      /* conv3d_k3_wgrad_c1_kernel: first layer (Cin = 1) */
+#define DRAM_K3_FWD_C1 8        /* conv3d_k3_fwd_c1_kernel: first layer (Cin = 1), HBM-bound vector kernel */
+#define DRAM_K3_WGRAD_WZY 9     /* conv3d_k3_wgrad_wzy_kernel: transposed F(2x2,3x3) over (z,y) */
+#define DRAM_K3_KINDS 10
+
+/* forward / backward-data of [N,Cin,D,H,W] -> Cout channels; the destination may be split over two tensors as in
+ * dram_conv3d_k3_fwd_ex (dstC2 = 0: one tensor); fused != 0: the dram_conv3d_k3_fwd_fused variant. */
+int dram_conv3d_k3_fwd_choice(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
+                              int dstW2, int fused, char* name, size_t cap);
+/* backward-weights with x = x1[.,C1,..] ++ crop(x2[.,C2,..]) (C2 = 0: one tensor); lazy != 0: the *_fused variant
+ * with at least one lazily normalised source. */
+int dram_conv3d_k3_wgrad_choice(int N, int C1, int C2, int Cout, int D, int H, int W, int lazy, char* name, size_t cap);
+/* launches per kernel family (index = DRAM_K3_*) since the library was loaded, into counts[0..n) */
+int dram_conv3d_k3_launch_counts(unsigned long long* counts, int n);
+
 /* Training-mode BatchNorm / GroupNorm statistics (parts.py:19-31) from the conv epilogue's partials: save_mean,
  * save_rstd per statistic, rowcoef[N*C][2], running statistics updated as dram_norm_fwd_train does.  Chan's
  * combine in fp64; a total count that differs from the statistic's population poisons it with NaN. */

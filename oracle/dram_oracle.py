@@ -517,6 +517,8 @@ ST_DRAM_REF_ATT_MODEL = dict(ST_DRAM_REF_MODEL, **{     # dram/exp_settings/st_d
 PCM_DOT_MERGES = ("sm", "scaled_dot_product", "scaled_dot_product_relu", "smrelu", "smscaled", "l2sm", "l2smrelu")
 PCM_GEO_MERGES = ("scaled_dot_product_geo", "scaled_dot_product_geo_relu", "att_is_all")     # models.py:287-299
 PCM_SUM_MERGES = ("cosine", "heu1", "heu2")                                                   # models.py:300-302, 307-320
+PCM_L2_MERGE = "l2"      # models.py:262-264: exp(-5 (theta - phi)^2) / sum over the edges; its broadcast and the reshape of
+                         # compute_cross_x (models.py:396) are only defined for f_dim == 1
 
 
 def pcm_geo_feature(p_enc_dim, spatial, dtype=torch.float32):
@@ -580,7 +582,7 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
     """PCM.forward (models.py:333-363) as dense tensor algebra.
     p: {"theta.weight", "theta.bias", "phi.*", "G.*", "r.*", "geo_theta.*", "geo_phi.*"} (absent = Identity,
     models.py:169-192).  cam [B, g_ch, D, H, W], f [B, in_ch, D, H, W] -> refined cam [B, g_ch, D, H, W]."""
-    if merge_type not in PCM_DOT_MERGES + PCM_GEO_MERGES + PCM_SUM_MERGES:
+    if merge_type not in PCM_DOT_MERGES + PCM_GEO_MERGES + PCM_SUM_MERGES + (PCM_L2_MERGE,):
         raise NotImplementedError(merge_type)
     B, _, D, H, W = f.shape
     offs = pcm_offsets(k_size, connectivity, self_loop)
@@ -602,15 +604,21 @@ def pcm_forward(p, cam, f, k_size=3, connectivity=2, self_loop=True, merge_type=
             l1 = torch.stack([(th - shifted(ph, o)).abs().sum(1) for o in offs], dim=1)
             v = dot / (1.0 + l1)
             if merge_type == "heu1":
-                with torch.no_grad():
-                    mask = torch.ones_like(v)
+                with torch.no_grad():       # models.py:311-314: the masked f is formed INSIDE no_grad -- it (and with it
+                    mask = torch.ones_like(v)           # the whole heu1 attention) carries no gradient to theta / phi
                     mask[v < 0.03] = 0.0
-                v = v * mask
+                    v = v * mask
             else:
                 v = F.relu(v)
             eps = 1e-7
         v = v * valid
         a = v / (eps + v.sum(1, keepdim=True))
+    elif merge_type == PCM_L2_MERGE:                                        # models.py:262-264
+        if th.shape[1] != 1:
+            raise ValueError("PCM merge_type 'l2' is only defined for f_dim == 1 (models.py:263 broadcasts [.., 1, f_dim] "
+                             "against [.., f_dim, edges], models.py:396 reshapes the result to one row per node)")
+        v = torch.cat([torch.exp(5.0 * (-(th - shifted(ph, o)) ** 2)) for o in offs], dim=1) * valid
+        a = v / v.sum(1, keepdim=True)
     elif merge_type in PCM_GEO_MERGES:                                      # models.py:287-299
         geo = pcm_geo_feature(p_enc_dim, (D, H, W), f.dtype).unsqueeze(0).expand(B, -1, D, H, W)
         gth, gph = _lin(p, "geo_theta", geo), _lin(p, "geo_phi", geo)
@@ -682,10 +690,13 @@ def pcm_forward_literal(p, cam, f, k_size=3, connectivity=2, self_loop=True,
                             with torch.no_grad():
                                 mask_f = torch.ones_like(fm)
                                 mask_f[fm < 0.03] = 0.0
-                            fm = fm * mask_f
+                                fm = fm * mask_f
                         else:
                             fm = F.relu(fm)
                         f_sm = fm / (1e-7 + fm.sum(dim=-1, keepdim=True))
+                elif merge_type == PCM_L2_MERGE:                                           # merge_func, models.py:262-264
+                    fm = torch.exp(5.0 * (-(x_theta - x_phi) ** 2))
+                    f_sm = fm / fm.sum(dim=-1, keepdim=True)
                 else:
                     f_sm = F.softmax(fm, dim=-1)
                 x_g = lin("G", cam_agg).permute(1, 0, 2)                                  # [B, E, g_dim]

@@ -1,0 +1,171 @@
+"""Value checks on the workload bench.py times: DC3D(st_dram_ref) at full channel widths on 128^3 chunks, through the fused
+engine, in the memory mode ('tight': every large activation lazy, upsampled-input stages in slices of samples) and on the
+kernels (Winograd-(z,y) forward / backward-data with 4 x-boxes per row, lazy backward-weights over 128^3 volumes, sample
+offsets beyond 2^32 elements, statistics finalised over slices) that the 64 x 128^3 step runs.
+
+  (a) anchor: ONE chunk of 128^3 against the oracle on the CPU (reference dram/models.py:120-147, dram/parts.py:177-187):
+      output and every parameter gradient with GroupNorm(1, C) ('ln'); with BatchNorm the output against the oracle at
+      2 x 64^3 and the whole step against the per-op path at 1 x 128^3;
+  (b) scale: the same chunk replicated to the benchmark's 64 chunks, engine in 'tight' mode: every sample's output equals
+      sample 0's = the N = 1 output, every parameter gradient is 64 x the N = 1 gradient -- with BatchNorm too (the
+      statistics of 64 identical chunks are those of one), which is the mode bench.py runs;
+  (c) what ran: the library's launch counters show the (z,y) forward kernel and the lazy backward-weights kernel.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dram_oracle as O
+from dram_amd.configs import ST_DRAM_REF_MODEL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _model(norm, seed=0, away_from_zero=False):
+    """DC3D(st_dram_ref) with HeNorm weights and non-trivial affine norm parameters.  `away_from_zero`: biases of +-3 sigma,
+    so that no pre-activation lies within rounding of the ReLU threshold when two device paths are compared with each other
+    (tests/test_gpu_engine.py explains the mask-flip mechanism)."""
+    import models
+    torch.manual_seed(seed)
+    m = models.DC3D(**ST_DRAM_REF_MODEL, norm_method=norm)
+    m.init(models.HeNorm(mode="fan_in"))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.BatchNorm3d, torch.nn.GroupNorm)) and mod.weight is not None:
+                mod.weight.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+                if away_from_zero:
+                    sign = torch.where(torch.arange(mod.bias.numel()) % 3 == 2, -1.0, 1.0)
+                    mod.bias.copy_(3.0 * sign * mod.weight.abs())
+                else:
+                    mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+    return m
+
+
+def _chunk(n, s, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 1, s, s, s, generator=g)
+    gout = (0.5 + torch.rand(n, 1, s, s, s, generator=g)) / (s ** 3)       # positive: no cancelling sums in the last layers
+    return x, gout
+
+
+def _device_step(model, x, gout, fused=True):
+    from dram_amd import functional as HF
+    model.fused = fused
+    for p in model.parameters():
+        p.grad = None
+    before = HF.conv_launch_counts()
+    out, same = model(x)
+    assert out is same
+    (out * gout).sum().backward()
+    torch.cuda.synchronize()
+    delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
+    return out.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, delta
+
+
+def _oracle_step(model_cpu_sd, x, gout, norm, want_grads=True):
+    params, buffers = O.split_state_dict({k: v.clone() for k, v in model_cpu_sd.items()})
+    for p in params.values():
+        p.requires_grad_(want_grads)
+    with torch.set_grad_enabled(want_grads):
+        out = O.dc3d_forward(ST_DRAM_REF_MODEL, params, buffers, x, training=True, norm_method=norm, use_checkpoint=False)
+        if want_grads:
+            (out * gout).sum().backward()
+    return out.detach(), ({k: p.grad for k, p in params.items()} if want_grads else None)
+
+
+def test_full_width_128_groupnorm_matches_the_oracle():
+    """(a) 1 x 128^3, 'ln', fused engine vs the CPU oracle: output <= 1e-4, every parameter gradient <= 5e-4."""
+    from dram_amd import functional as HF
+    torch.set_num_threads(16)
+    model = _model("ln")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x, gout = _chunk(1, 128, 21)
+    ref_out, ref_g = _oracle_step(sd, x, gout, "ln")
+    model = model.to(DEV).train()
+    out, grads, delta = _device_step(model, x.to(DEV), gout.to(DEV))
+    assert delta[HF.K3_FWD_WZY] >= 16, delta           # the (z,y) kernel on the 128^3 / 64^3 / 32^3 levels, both directions
+    assert delta[HF.K3_WGRAD_WZ_LAZY] + delta[HF.K3_WGRAD_WZ] + delta[HF.K3_WGRAD_WZY] >= 13, delta
+    assert _rel(out, ref_out) <= 1e-4, _rel(out, ref_out)
+    errs = {k: _rel(grads[k], ref_g[k]) for k in ref_g}
+    print(f"\nDC3D(st_dram_ref, ln) 1x128^3, engine vs oracle: out {_rel(out, ref_out):.2e}, worst gradient {max(errs.values()):.2e}")
+    bad = {k: v for k, v in errs.items() if v > 5e-4}
+    assert not bad, bad
+
+
+def test_full_width_batchnorm_matches_the_oracle_and_the_per_op_path():
+    """(a) 'bn': output vs the CPU oracle at 2 x 64^3 (<= 1e-4); at 1 x 128^3 the fused step equals the per-op step (the
+    path the reference's block goldens pin) on outputs, gradients and BatchNorm buffers to 1e-4."""
+    torch.set_num_threads(16)
+    model = _model("bn", seed=3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x, gout = _chunk(2, 64, 22)
+    ref_out, _ = _oracle_step(sd, x, gout, "bn", want_grads=False)
+    model = model.to(DEV).train()
+    out, _, _ = _device_step(model, x.to(DEV), gout.to(DEV))
+    assert _rel(out, ref_out) <= 1e-4, _rel(out, ref_out)
+    del model
+    # fused vs per-op at the benchmark's chunk size, pre-activations kept away from the ReLU threshold
+    model = _model("bn", seed=4, away_from_zero=True).to(DEV).train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    x, gout = _chunk(1, 128, 23)
+    x, gout = x.to(DEV), gout.to(DEV)
+    o_ref, g_ref, _ = _device_step(model, x, gout, fused=False)
+    buf_ref = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    model.load_state_dict(sd0)
+    o_got, g_got, delta = _device_step(model, x, gout, fused=True)
+    assert _rel(o_got, o_ref) <= 2e-5, _rel(o_got, o_ref)
+    errs = {k: _rel(g_got[k], g_ref[k]) for k in g_ref}
+    print(f"\nDC3D(st_dram_ref, bn) 1x128^3, engine vs per-op: out {_rel(o_got, o_ref):.2e}, worst gradient {max(errs.values()):.2e}")
+    bad = {k: v for k, v in errs.items() if v > 1e-4}
+    assert not bad, bad
+    for k, v in buf_ref.items():
+        assert _rel(model.state_dict()[k].double(), v.double()) <= 1e-5, k
+
+
+@pytest.mark.parametrize("norm", ["bn", "ln"])
+def test_benchmark_batch_of_64_replicated_chunks(norm, monkeypatch):
+    """(b) + (c): 64 copies of one 128^3 chunk through the engine exactly as bench.py runs it -- one batch, memory mode
+    'tight' (chosen by the engine itself for this size), the widest stage in slices of samples, lazy backward-weights --
+    must give 64 equal outputs, equal to the N = 1 run's, and 64 x its parameter gradients."""
+    from dram_amd import engine
+    from dram_amd import functional as HF
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 262 * 2 ** 30:
+        pytest.skip(f"needs the 251 GB the benchmark step takes; {free / 2 ** 30:.0f} GB free")
+    N = 64
+    model = _model(norm, seed=5, away_from_zero=True).to(DEV).train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    x1, g1 = _chunk(1, 128, 24)
+    x1, g1 = x1.to(DEV), g1.to(DEV)
+    o1, grads1, _ = _device_step(model, x1, g1)
+    plan1 = engine.LAST_PLAN
+    model.load_state_dict(sd0)
+    x = x1.expand(N, -1, -1, -1, -1).contiguous()
+    gout = g1.expand(N, -1, -1, -1, -1).contiguous()
+    assert x.numel() * 64 > 2 ** 32                       # a 64-channel activation of this batch: offsets beyond 2^32 elements
+    torch.cuda.reset_peak_memory_stats()
+    o, grads, delta = _device_step(model, x, gout)
+    plan = engine.LAST_PLAN
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    # (c) the mode and the kernels of the benchmark
+    assert plan.mode == "tight" and plan.sliced_stages >= 1 and plan1.sliced_stages == 0, (plan.mode, plan.sliced_stages)
+    assert delta[HF.K3_FWD_WZY] >= 16 and delta[HF.K3_WGRAD_WZ_LAZY] + delta[HF.K3_WGRAD_WZY] >= 8, delta
+    # (b) every sample equals sample 0 equals the single-chunk run
+    worst_out = max(_rel(o[n], o[0]) for n in range(1, N))
+    assert worst_out <= 1e-6, worst_out
+    assert _rel(o[0], o1[0]) <= 2e-5, _rel(o[0], o1[0])
+    errs = {k: _rel(grads[k], N * grads1[k]) for k in grads1}
+    print(f"\n{norm}: 64 x 128^3 as one batch ('tight', {plan.sliced_stages} sliced stage(s), peak {peak:.0f} GB): samples differ by "
+          f"{worst_out:.1e}, out vs N=1 {_rel(o[0], o1[0]):.1e}, worst gradient vs 64 x N=1 {max(errs.values()):.1e}")
+    bad = {k: v for k, v in errs.items() if v > 1e-4}
+    assert not bad, bad
+    del o, grads, x, gout
+    torch.cuda.empty_cache()

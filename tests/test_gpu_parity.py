@@ -122,8 +122,9 @@ def test_conv3d_k3_virtual_concat(shape):
 
 
 def test_conv3d_k3_wzy_kernel_is_selected():
-    """The shapes above that are meant for the Winograd-(z,y) kernel really select it (host rule mirrored in
-    functional.conv_fwd_kernel_name, csrc/conv3d_k3.hip use_wzy)."""
+    """The shapes above that are meant for the Winograd-(z,y) kernel really launch it: the library is asked what it
+    chooses (dram_conv3d_k3_fwd_choice, the same fwd_choice the launch goes through; there is no host-side copy of the
+    rule), and its launch counters are read around a real call."""
     from dram_amd import functional as HF
     assert HF.conv_fwd_kernel_name((11, 8, 32), 128, 64) == "conv3d_k3_fwd_wzy_kernel"
     assert HF.conv_fwd_kernel_name((11, 8, 32), 64, 128, fused=True) == "conv3d_k3_fwd_wzy_kernel"
@@ -133,6 +134,17 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     assert "wz_kernel" in HF.conv_fwd_kernel_name((3, 9, 70), 64, 64)          # too much padding
     assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 32), 16, 64)          # 16 output channels
     assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel"
+    # what a launch really does: forward (64 -> 128) and backward-data (128 -> 64) on the (z,y) kernel, backward-weights on
+    # the transposed Winograd kernel
+    before = HF.conv_launch_counts()
+    x = dev(torch.randn(1, 64, 4, 8, 32, generator=g(31))).requires_grad_(True)
+    w = dev(torch.randn(128, 64, 3, 3, 3, generator=g(32)) * 0.05).requires_grad_(True)
+    HF.conv3d_k3(x, w).sum().backward()
+    torch.cuda.synchronize()
+    after = HF.conv_launch_counts()
+    delta = [a - b for a, b in zip(after, before)]
+    assert delta[HF.K3_FWD_WZY] == 2, delta
+    assert delta[HF.K3_WGRAD_WZ] + delta[HF.K3_WGRAD_WZY] == 1 and sum(delta) == 3, delta
 
 
 def test_conv3d_k3_wzy_concat_and_split():

@@ -144,6 +144,40 @@ def test_pcm_sum_merges_match_oracle(merge, shape, self_loop, iters, residual, c
     assert rel(out, ref) <= TOL
     assert rel(camg.grad, cam64.grad) <= TOL
     assert rel(fg.grad, f64.grad) <= TOL
+    scale = max(v.grad.abs().max().item() for v in p64.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        if merge == "heu1" and k.startswith(("theta", "phi")):
+            # reference models.py:311-314: the masked similarities are formed under no_grad -- no gradient reaches theta / phi
+            assert p64[k].grad is None and (p.grad is None or p.grad.abs().max().item() == 0.0), k
+            continue
+        err = (p.grad.detach().cpu().double() - p64[k].grad).abs().max().item()
+        assert err <= TOL * max(scale, 1e-30), (k, err, scale)
+
+
+@pytest.mark.parametrize("shape,self_loop,conn", [((5, 4, 7), False, 2), ((1, 2, 3), True, 2), ((4, 5, 6), True, 3)])
+def test_pcm_l2_merge_matches_oracle(shape, self_loop, conn):
+    """merge_type 'l2' (the constructor default, models.py:238,262-264) for f_dim == 1, the one width for which the reference's
+    broadcast and reshape are defined; any other width raises.  PARITY UNPINNED like all of PCM; against the oracle's fp64
+    restatement (which spells out the reference's exp / sum form), values and every gradient."""
+    import models
+    torch.manual_seed(11)
+    B, C, G, Gd = 2, 6, 2, 3
+    m = models.PCM(shape, C, G, 1, 0, Gd, 1, 3, merge_type="l2", self_loop=self_loop, connectivity=conn, p_enc_dim=0)
+    g = torch.Generator().manual_seed(12)
+    cam = torch.randn((B, G) + shape, generator=g)
+    f = torch.rand((B, C) + shape, generator=g)
+    gout = torch.randn((B, G) + shape, generator=g)
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    cam64, f64 = cam.double().requires_grad_(True), f.double().requires_grad_(True)
+    ref = O.pcm_forward(p64, cam64, f64, 3, conn, self_loop, "l2", 1, False)
+    (ref * gout.double()).sum().backward()
+    m = m.cuda()
+    camg, fg = cam.cuda().requires_grad_(True), f.cuda().requires_grad_(True)
+    out = m(camg, fg)
+    (out * gout.cuda()).sum().backward()
+    assert rel(out, ref) <= TOL
+    assert rel(camg.grad, cam64.grad) <= TOL
+    assert rel(fg.grad, f64.grad) <= TOL
     scale = max(v.grad.abs().max().item() for v in p64.values())
     for k, p in m.named_parameters():
         err = (p.grad.detach().cpu().double() - p64[k].grad).abs().max().item()
@@ -161,8 +195,11 @@ def test_pcm_offsets_match_oracle():
             for k in (3, 5):
                 m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, k, merge_type="sm", self_loop=sl, connectivity=conn, p_enc_dim=0)
                 assert sorted(m.init_graph()) == sorted(tuple(int(v) for v in o) for o in O.pcm_offsets(k, conn, sl))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="f_dim == 1"):      # 'l2' with f_dim = 2: the reference's broadcast is undefined
         m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, 3, merge_type="l2", p_enc_dim=0).cuda()
+        m(torch.zeros(1, 1, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        m = models.PCM((4, 4, 4), 3, 1, 2, 0, 2, 1, 3, merge_type="no_such_merge", p_enc_dim=0).cuda()
         m(torch.zeros(1, 1, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
 
 

@@ -47,6 +47,33 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(4, 64, 64, 128, 128, 128) > 0
 
 
+def test_kernel_choice_queries():
+    """dram_conv3d_k3_fwd_choice / dram_conv3d_k3_wgrad_choice are pure functions of the shape (no GPU needed): the
+    benchmark's layers (DC3D st_dram_ref at 128^3) get the kernels DESIGN.md names, and the two rules the old host-side
+    copy of use_wzy had dropped are there."""
+    from dram_amd import functional as HF
+    S = (128, 128, 128)
+    assert HF.conv_fwd_kernel_name(S, 64, 32, fused=True) == "conv3d_k3_fwd_wzy_kernel"           # ds0.1 forward
+    assert HF.conv_fwd_kernel_name(S, 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel"          # us2.0 forward
+    # us2.0 backward-data: 64 -> 128 + 64 channels over two tensors (boundary at 128: a multiple of 32)
+    assert HF.conv_fwd_kernel_name(S, 192, 64, dst_split=(128, 64, 128, 128, 128)) == "conv3d_k3_fwd_wzy_kernel"
+    # a split at a channel that is not a multiple of 32 cannot take the (z,y) kernel (one destination tensor per wave)
+    assert "fwd_wz_kernel" in HF.conv_fwd_kernel_name((8, 8, 32), 192, 64, dst_split=(112, 80, 8, 8, 32))
+    # ds0.1 backward-data 64 -> 32: Cout % 64 != 0
+    name = HF.conv_fwd_kernel_name(S, 32, 64)
+    assert name in ("conv3d_k3_fwd_wz_kernel<32, 4, 1, false>", "conv3d_k3_fwd_wzy_kernel"), name
+    # first layer
+    assert HF.conv_fwd_kernel_name(S, 32, 1, fused=True) in ("conv3d_k3_fwd_kernel<32, 4, 2, 1, true>", "conv3d_k3_fwd_c1_kernel")
+    assert HF.conv_fwd_kernel_name((16, 16, 16), 512, 256, fused=True) == "conv3d_k3_fwd_wz_kernel<16, 8, 2, true>"
+    wz = HF.conv_wgrad_kernel_name(64, S, 64, 128, 64, lazy=True)
+    assert wz in ("conv3d_k3_wgrad_wz_kernel<16, 2, 4, 2, true>", "conv3d_k3_wgrad_wzy_kernel<true>"), wz
+    assert HF.conv_wgrad_kernel_name(64, S, 32, 1) == "conv3d_k3_wgrad_c1_kernel"
+    assert "wgrad_wz" not in HF.conv_wgrad_kernel_name(2, (5, 7, 11), 16, 8)              # odd width: direct kernel
+    assert HF.conv_wgrad_kernel_name(2, (5, 7, 11), 16, 8, lazy=True) == HF.conv_wgrad_kernel_name(2, (5, 7, 11), 16, 8)
+    counts = HF.conv_launch_counts()
+    assert len(counts) == HF.K3_KINDS and all(c >= 0 for c in counts)
+
+
 def test_cpu_tensors_fail_loudly():
     import parts
     blk = parts.ConvBlock5d([2, 3], [3, 4], 0, 3, False, 1, 0.0)

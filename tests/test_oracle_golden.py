@@ -201,6 +201,30 @@ def test_pcm_sum_merges_dense_restatement_equals_literal_one(merge):
         assert (a - b).abs().max().item() < 1e-10
 
 
+def test_pcm_l2_and_heu1_gradient_semantics():
+    """PARITY UNPINNED (DGL absent).  'l2' (models.py:262-264, f_dim = 1): the dense restatement equals the literal one, which
+    spells the reference's expression out.  'heu1' (models.py:307-314): the masked similarities are formed under no_grad, so the
+    attention is a constant of the graph -- theta / phi receive no gradient in either restatement."""
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) + 0.1
+    p = {"theta.weight": r(1, 5), "theta.bias": r(1), "phi.weight": r(1, 5), "phi.bias": r(1),
+         "G.weight": r(3, 2), "G.bias": r(3), "r.weight": r(2, 3), "r.bias": r(2)}
+    for shape in [(4, 3, 5), (1, 2, 3)]:
+        cam, f = r(2, 2, *shape), r(2, 5, *shape)
+        a = O.pcm_forward(p, cam, f, 3, 2, False, "l2")
+        b = O.pcm_forward_literal(p, cam, f, 3, 2, False, "l2")
+        assert (a - b).abs().max().item() < 1e-10
+    with pytest.raises(ValueError):
+        O.pcm_forward({**p, "theta.weight": r(2, 5), "theta.bias": r(2), "phi.weight": r(2, 5), "phi.bias": r(2)},
+                      r(1, 2, 2, 2, 2), r(1, 5, 2, 2, 2), 3, 2, False, "l2")
+    p4 = {"theta.weight": r(4, 5), "theta.bias": r(4), "phi.weight": r(4, 5), "phi.bias": r(4),
+          "G.weight": r(3, 2), "G.bias": r(3), "r.weight": r(2, 3), "r.bias": r(2)}
+    for fwd in (O.pcm_forward, O.pcm_forward_literal):
+        q = {k: v.clone().requires_grad_(True) for k, v in p4.items()}
+        fwd(q, r(2, 2, 3, 2, 3), r(2, 5, 3, 2, 3), 3, 2, False, "heu1").sum().backward()
+        assert q["theta.weight"].grad is None and q["phi.weight"].grad is None and q["G.weight"].grad is not None
+
+
 @pytest.mark.parametrize("merge", O.PCM_GEO_MERGES)
 @pytest.mark.parametrize("geo_f", [4, 0])
 def test_pcm_geo_dense_restatement_equals_literal_one(merge, geo_f):
