@@ -69,7 +69,46 @@ def _device_step(model, x, gout, fused=True):
     return out.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, delta
 
 
-def _oracle_step(model_cpu_sd, x, gout, norm, want_grads=True):
+class _ConvTap:
+    """Records, for every 3x3x3 / 1x1x1 convolution the oracle runs, its input tensor and the gradient of its output (keyed by
+    the weight tensor), so that individual weight-gradient entries can be recomputed EXACTLY (fp64 dot products over the
+    volume).  Needed because torch's fp32 CPU convolution -- the oracle's arithmetic -- is itself off by up to 3e-3 of
+    max|dW| on the backward-weights of 128^3 volumes (sums of 2 M products; scripts/diag_wgrad_accuracy_128.py measures it
+    against exact fp64 values: torch-CPU 2e-4 on sampled entries, the HIP kernels 1e-7)."""
+
+    def __init__(self):
+        self.x, self.dy, self._orig = {}, {}, O.conv3d
+
+    def __enter__(self):
+        def conv3d(x, w, bias=None, pad=1):
+            y = self._orig(x, w, bias, pad)
+            if y.requires_grad:
+                self.x[id(w)] = x.detach()
+                y.register_hook(lambda g, k=id(w): self.dy.__setitem__(k, g.detach()))
+            return y
+        O.conv3d = conv3d
+        return self
+
+    def __exit__(self, *exc):
+        O.conv3d = self._orig
+
+    def exact_entries(self, w, n, rng):
+        """[(index, exact fp64 value)] for `n` random entries of dW, from the oracle's own operands."""
+        import torch.nn.functional as F
+        x, dy = self.x[id(w)], self.dy[id(w)]
+        k = w.shape[-1]
+        D, H, W = x.shape[2:]
+        out = []
+        for _ in range(n):
+            co, ci = int(rng.integers(w.shape[0])), int(rng.integers(w.shape[1]))
+            kz, ky, kx = (int(rng.integers(k)) for _ in range(3))
+            xp = F.pad(x[:, ci].double(), (k // 2,) * 6)
+            val = (dy[:, co].double() * xp[:, kz:kz + D, ky:ky + H, kx:kx + W]).sum().item()
+            out.append(((co, ci, kz, ky, kx), val))
+        return out
+
+
+def _oracle_step(model_cpu_sd, x, gout, norm, want_grads=True, tap=None):
     params, buffers = O.split_state_dict({k: v.clone() for k, v in model_cpu_sd.items()})
     for p in params.values():
         p.requires_grad_(want_grads)
@@ -77,26 +116,47 @@ def _oracle_step(model_cpu_sd, x, gout, norm, want_grads=True):
         out = O.dc3d_forward(ST_DRAM_REF_MODEL, params, buffers, x, training=True, norm_method=norm, use_checkpoint=False)
         if want_grads:
             (out * gout).sum().backward()
+    if tap is not None:
+        return out.detach(), params
     return out.detach(), ({k: p.grad for k, p in params.items()} if want_grads else None)
 
 
 def test_full_width_128_groupnorm_matches_the_oracle():
-    """(a) 1 x 128^3, 'ln', fused engine vs the CPU oracle: output <= 1e-4, every parameter gradient <= 5e-4."""
+    """(a) 1 x 128^3, 'ln', fused engine vs the CPU oracle: output <= 1e-4; norm parameters and the head <= 5e-4 against the
+    oracle's gradients; every conv weight gradient <= 2e-5 of max|dW| on 24 random entries against their EXACT values (fp64
+    sums over the volume of the oracle's operands), and <= 1e-2 as a whole tensor against the oracle's fp32 gradient (the bound
+    is torch-CPU's own error at this size, see _ConvTap)."""
     from dram_amd import functional as HF
     torch.set_num_threads(16)
     model = _model("ln")
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     x, gout = _chunk(1, 128, 21)
-    ref_out, ref_g = _oracle_step(sd, x, gout, "ln")
+    with _ConvTap() as tap:
+        ref_out, params = _oracle_step(sd, x, gout, "ln", tap=tap)
     model = model.to(DEV).train()
     out, grads, delta = _device_step(model, x.to(DEV), gout.to(DEV))
     assert delta[HF.K3_FWD_WZY] >= 16, delta           # the (z,y) kernel on the 128^3 / 64^3 / 32^3 levels, both directions
     assert delta[HF.K3_WGRAD_WZ_LAZY] + delta[HF.K3_WGRAD_WZ] + delta[HF.K3_WGRAD_WZY] >= 13, delta
     assert _rel(out, ref_out) <= 1e-4, _rel(out, ref_out)
-    errs = {k: _rel(grads[k], ref_g[k]) for k in ref_g}
-    print(f"\nDC3D(st_dram_ref, ln) 1x128^3, engine vs oracle: out {_rel(out, ref_out):.2e}, worst gradient {max(errs.values()):.2e}")
-    bad = {k: v for k, v in errs.items() if v > 5e-4}
-    assert not bad, bad
+    rng = np.random.default_rng(0)
+    worst_exact = worst_small = worst_whole = 0.0
+    for k, p in params.items():
+        got = grads[k].double().cpu()
+        if p.dim() == 5:
+            scale = p.grad.abs().max().item()
+            for idx, val in tap.exact_entries(p, 24, rng):
+                err = abs(got[idx].item() - val) / scale
+                worst_exact = max(worst_exact, err)
+                assert err <= 2e-5, (k, idx, got[idx].item(), val, scale)
+            e = _rel(got, p.grad)
+            worst_whole = max(worst_whole, e)
+            assert e <= 1e-2, (k, e)
+        else:
+            e = _rel(got, p.grad)
+            worst_small = max(worst_small, e)
+            assert e <= 5e-4, (k, e)
+    print(f"\nDC3D(st_dram_ref, ln) 1x128^3, engine vs oracle: out {_rel(out, ref_out):.2e}; conv weight gradients vs exact fp64 "
+          f"entries {worst_exact:.1e}, vs torch-CPU fp32 {worst_whole:.1e}; norm / bias gradients {worst_small:.1e}")
 
 
 def test_full_width_batchnorm_matches_the_oracle_and_the_per_op_path():

@@ -182,3 +182,45 @@ def test_fused_engine_sliced_and_fully_lazy(monkeypatch):
     assert _rel(got[2], ref[2]) <= 1e-4
     for k, v in ref[3].items():
         assert _rel(got[3][k].double(), v.double()) <= 1e-5, k
+
+
+def test_backward_uses_the_plan_of_its_own_forward(monkeypatch):
+    """The memory decisions of a forward call (what is written, what is kept, how an upsampled-input stage is sliced) live on
+    that call's tape: another forward in between -- here one with every threshold changed and a different batch -- must not
+    change how the pending backward slices and what it computes."""
+    import models
+    from dram_amd import engine
+    torch.manual_seed(11)
+    model = models.DC3D(**SLIM)
+    model.init(models.HeNorm(mode="fan_in"))
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand((3, 1, 16, 16, 16), generator=g).to(DEV)
+    gout = ((0.5 + torch.rand((3, 1, 16, 16, 16), generator=g)) / x.numel()).to(DEV)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    monkeypatch.setattr(engine, "MEMORY_MODE", "manual")
+
+    def step(interleave):
+        model.load_state_dict(sd0)
+        for p in model.parameters():
+            p.grad = None
+        monkeypatch.setattr(engine, "MATERIALISE_BELOW", 0.0)
+        monkeypatch.setattr(engine, "KEEP_UPSAMPLED_BELOW", 0.0)
+        monkeypatch.setattr(engine, "SLICE_UPSAMPLED_ABOVE", 1e-12)        # slices of one sample
+        out, _ = model(x)
+        assert engine.LAST_PLAN.sliced_stages == 3
+        if interleave:
+            monkeypatch.setattr(engine, "MATERIALISE_BELOW", 1.0)
+            monkeypatch.setattr(engine, "KEEP_UPSAMPLED_BELOW", 1.0)
+            monkeypatch.setattr(engine, "SLICE_UPSAMPLED_ABOVE", 1.0)
+            with torch.no_grad():
+                model.eval()
+                model(x[:2])
+                model.train()
+            assert engine.LAST_PLAN.sliced_stages == 0
+        (out * gout).sum().backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    a, b = step(False), step(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
