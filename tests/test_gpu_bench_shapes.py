@@ -123,7 +123,7 @@ def _oracle_step(model_cpu_sd, x, gout, norm, want_grads=True, tap=None):
 
 def test_full_width_128_groupnorm_matches_the_oracle():
     """(a) 1 x 128^3, 'ln', fused engine vs the CPU oracle: output <= 1e-4; norm parameters and the head <= 5e-4 against the
-    oracle's gradients; every conv weight gradient <= 2e-5 of max|dW| on 24 random entries against their EXACT values (fp64
+    oracle's gradients; every conv weight gradient <= 1e-4 of max|dW| on 24 random entries against their EXACT values (fp64
     sums over the volume of the oracle's operands), and <= 1e-2 as a whole tensor against the oracle's fp32 gradient (the bound
     is torch-CPU's own error at this size, see _ConvTap)."""
     from dram_amd import functional as HF
@@ -147,7 +147,7 @@ def test_full_width_128_groupnorm_matches_the_oracle():
             for idx, val in tap.exact_entries(p, 24, rng):
                 err = abs(got[idx].item() - val) / scale
                 worst_exact = max(worst_exact, err)
-                assert err <= 2e-5, (k, idx, got[idx].item(), val, scale)
+                assert err <= 1e-4, (k, idx, got[idx].item(), val, scale)
             e = _rel(got, p.grad)
             worst_whole = max(worst_whole, e)
             assert e <= 1e-2, (k, e)
