@@ -215,6 +215,52 @@ __device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lan
     }
 }
 
+// The same for NT 32-voxel tiles of ONE 32-channel tile per lane (16 registers each; tile t valid if OK(t)): per wave half and
+// channel the two-pass {mean, M2} over the <= 32 * NT valid values.
+template <int NT, typename YF, typename OKF>
+__device__ __forceinline__ void stats_epilogue_tiles(YF Y, OKF OK, int lane, float* __restrict__ stats, int64_t row0, int co0, int Cout,
+                                                     int nparts, int pidx) {
+    const int j = lane & 31, kh = lane >> 5;
+    const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    int nv = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) nv += __popcll(__ballot(OK(t)) & half);
+    const float nvalid = (float)nv;
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s[i] += OK(t) ? Y(t, i) : 0.f;
+    }
+    lane_transpose_reduce<16>(s, lane);
+    const float mean_j = nvalid > 0.f ? s[0] / nvalid : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    float q[16];
+    q[0] = mean_j;
+    lane_transpose_broadcast<16>(q, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float m = q[i];
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float d = Y(t, i) - m;
+            acc += OK(t) ? d * d : 0.f;
+        }
+        q[i] = acc;
+    }
+    lane_transpose_reduce<16>(q, lane);
+    const int i = j % 16;
+    const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+    if (j < 16 && co < Cout) {
+        float* o = stats + ((row0 + co) * (int64_t)nparts + pidx) * 3;
+        o[0] = mean_j;
+        o[1] = q[0];
+        o[2] = nvalid;
+    }
+}
+
 // Operand transform of a lazily normalised source (ConvArgs::coef1/2): per K-chunk channel the wave-uniform
 // {a, b, lo}: v -> max(a*v + b, lo), lo = 0 with ReLU and -inf without; identity {1, 0, -inf} for a plain source,
 // {0, 0, 0} for the channel tail beyond Cin.
@@ -437,6 +483,115 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
         const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + wave;
         stats_epilogue<COT>([&](int t, int i) { return acc[i >> 4][t][i & 15]; }, okt[0], okt[1], lane, a.stats,
                             (int64_t)n * a.Cout, co0, a.Cout, a.nparts, pidx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward of the FIRST layer (Cin == 1, e.g. DC3D ds_modules.0 conv 1->32, reference parts.py:177 with in_ch_list[0] = 1):
+// the one 3x3x3 conv of the network that is HBM-bound (13 FLOP/B, SURVEY F5: 4 B read + 4*Cout B written per voxel).  The
+// generic direct kernel pads the single input channel to a 4-channel K chunk and is then bound by matrix issue on zeros
+// (0.20 of the HBM roof).  Here the 27 taps are the GEMM's K dimension (as in conv3d_k3_wgrad_c1_kernel):
+//     Y[co][v] = sum_tap W[co][tap] * X[v + tap]        M = co (32 per tile), N = voxels, K = 27 (+1 zero)
+// on v_mfma_f32_32x32x2_f32: 14 MFMAs per 32 voxels x 32 channels (1.5 ms of matrix time for 64 x 128^3, under the ~3.5 ms
+// the bytes need).  A = the filter, 14 registers per lane for the whole block; B = one LDS read per MFMA whose address is a
+// loop-invariant per-lane register (halo position of the lane's voxel + its k-index's tap offset) plus an immediate per row.
+// Block = 32 x 8 x 4 voxels (8 KB halo in LDS), wave = one z plane = 8 rows of 32 voxels; a row's 16 accumulator registers
+// are stored as they complete (128-byte runs along x per channel: buffer stores, out-of-volume lanes and channel tails fall
+// out of the descriptor's range check) and stay in registers for the statistics epilogue (two-pass moments of the wave's
+// <= 256 outputs per channel -> one partial per (row, box, wave), as the other forward kernels write them).
+struct FwdC1Geom {
+    static constexpr int BX = 32, BY = 8, BZ = 4;
+    static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    static constexpr int HV = HX * HY * HZ;     // 2040
+    static constexpr int NQ = (HV + 255) / 256;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_c1_kernel(ConvArgs a) {
+    using G = FwdC1Geom;
+    constexpr int BY = G::BY, HX = G::HX, HY = G::HY, HV = G::HV, NQ = G::NQ;
+    __shared__ float lx[HV + 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, co tile), co tile fastest
+    const int co0 = (b % a.co_tiles) * 32; b /= a.co_tiles;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    const int n = b / a.nbz;
+    const int x0 = bx * G::BX, y0 = by * G::BY, z0 = bz * G::BZ;
+    const int D = a.D, H = a.H, W = a.W, Cout = a.Cout;
+    const int S = D * H * W;
+
+    // input halo -> LDS (zero padding by the descriptor's range check)
+    {
+        const __amdgpu_buffer_rsrc_t srx = make_rsrc(uniform_ptr(a.src.p1 + (size_t)n * S), 4u * (unsigned)S);
+        float v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q;
+            const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
+            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+            const int ok = (int)(e < HV) & (int)((unsigned)gx < (unsigned)W) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gz < (unsigned)D);
+            v[q] = buf_load(srx, ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (tid + 256 * q < HV) lx[tid + 256 * q] = v[q];
+    }
+    // A operand: W[co0 + j][tap = 2 s + kh] (tap 27: the zero that pads K to 28); B offsets of the lane's k index
+    float wa[14];
+    int boff[14];
+    {
+        const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 27u * 4u * (unsigned)Cout);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int tap = 2 * s + kh;
+            const int ok = (int)(tap < 27) & (int)(co0 + j < Cout);
+            wa[s] = buf_load(wsrd, ok ? 4u * (unsigned)(tap * Cout + co0 + j) : OOB, 0);
+            const int tp = tap < 27 ? tap : 0;
+            boff[s] = ((tp / 9 + wave) * HY + (tp / 3) % 3) * HX + tp % 3 + j;
+        }
+    }
+    __syncthreads();
+
+    // destination: one descriptor over sample n's [Cout][S] block; lane offset = its voxel + its 4 kh channels
+    const unsigned S4 = 4u * (unsigned)S;
+    const __amdgpu_buffer_rsrc_t dsrd = make_rsrc(uniform_ptr(a.dst.p1 + (size_t)n * Cout * S), (unsigned)Cout * S4);
+    const int gx = x0 + j, gz = z0 + wave;
+    const bool okxz = gx < W && gz < D;
+    const unsigned vbase = 4u * (unsigned)((gz * H + y0) * W + gx) + (unsigned)(co0 + 4 * kh) * S4;
+    float bias16[16];
+    const bool has_bias = a.bias != nullptr;
+    if (has_bias) {
+        const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(a.bias, 4u * (unsigned)Cout);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias16[r] = buf_load(bsrd, 4u * (unsigned)(co0 + 4 * kh + (r & 3) + 8 * (r >> 2)), 0);
+    }
+
+    f32x16 acc[BY];
+#pragma unroll
+    for (int t = 0; t < BY; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], lx[boff[s] + t * HX], acc[t], 0, 0, 0);
+        if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += bias16[r];
+        }
+        const unsigned voff = (okxz && (y0 + t) < H) ? vbase + 4u * (unsigned)(t * W) : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[t][r]), dsrd, (int)voff,
+                                                  (int)((unsigned)((r & 3) + 8 * (r >> 2)) * S4), 0);
+    }
+    if (a.stats) {
+        const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + wave;
+        stats_epilogue_tiles<BY>([&](int t, int i) { return acc[t][i]; }, [&](int t) { return okxz && (y0 + t) < H; }, lane, a.stats,
+                                 (int64_t)n * Cout, co0, Cout, a.nparts, pidx);
     }
 }
 
@@ -2320,6 +2475,7 @@ static bool use_wzy(const ConvArgs& a) {
 }
 
 struct FwdChoice {
+    bool c1;            // first-layer kernel (Cin = 1, plain source and destination)
     bool wz;
     bool wzy;
     int box;            // index into the kernel family's box table
@@ -2331,6 +2487,13 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
     c.wz = use_wz(a);
     c.wzy = use_wzy(a);
     c.parts_per_box = 4;
+    static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
+    c.c1 = !direct && a.Cin == 1 && a.src.p2 == nullptr && a.dst.p2 == nullptr && a.coef1 == nullptr;
+    if (c.c1) {
+        c.box = 0;
+        c.nbx = cdiv(a.W, FwdC1Geom::BX); c.nby = cdiv(a.H, FwdC1Geom::BY); c.nbz = cdiv(a.D, FwdC1Geom::BZ);
+        return c;
+    }
     if (c.wzy) {
         c.box = 0;
         c.nbx = cdiv(a.W, 32); c.nby = cdiv(a.H, 4); c.nbz = cdiv(a.D, 2);
@@ -2370,7 +2533,10 @@ static int fwd_kernel_id(const ConvArgs& a, const FwdChoice& c, char* name, size
     const int cot = a.Cout <= 32 ? 1 : 2;
     int kind;
     char buf[96];
-    if (c.wzy) {
+    if (c.c1) {
+        kind = DRAM_K3_FWD_C1;
+        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_c1_kernel");
+    } else if (c.wzy) {
         kind = DRAM_K3_FWD_WZY;
         snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wzy_kernel");
     } else if (c.wz) {
@@ -2392,6 +2558,17 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     if (a.stats) {
         DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * c.parts_per_box, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
                      "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * c.parts_per_box);
+    }
+    if (c.c1) {
+        a.nbx = c.nbx; a.nby = c.nby; a.nbz = c.nbz;
+        a.co_tiles = cdiv(a.Cout, 32);
+        const int64_t total = (int64_t)a.N * c.nbx * c.nby * c.nbz * a.co_tiles;
+        if (total > 0x7fffffffLL) {
+            set_error("conv3d_k3_fwd: grid too large");
+            return DRAM_EINVAL;
+        }
+        hipLaunchKernelGGL(conv3d_k3_fwd_c1_kernel, dim3((unsigned)total), dim3(256), 0, st, a);
+        return check_launch("conv3d_k3_fwd(c1)");
     }
     if (c.wzy) {
         a.wt += (size_t)63 * a.Cin * a.Cout;      // ... and the (z,y)-transformed ones follow those
