@@ -496,9 +496,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_kernel(ConvArgs a) {
 // the bytes need).  A = the filter, 14 registers per lane for the whole block; B = one LDS read per MFMA whose address is a
 // loop-invariant per-lane register (halo position of the lane's voxel + its k-index's tap offset) plus an immediate per row.
 // Block = 32 x 8 x 4 voxels (8 KB halo in LDS), wave = one z plane = 8 rows of 32 voxels; a row's 16 accumulator registers
-// are stored as they complete (128-byte runs along x per channel: buffer stores, out-of-volume lanes and channel tails fall
-// out of the descriptor's range check) and stay in registers for the statistics epilogue (two-pass moments of the wave's
-// <= 256 outputs per channel -> one partial per (row, box, wave), as the other forward kernels write them).
+// are stored as they complete (128-byte runs along x per channel: buffer stores, out-of-volume lanes fall out of the
+// descriptor's range check) and stay in registers for the statistics epilogue of their group of four rows (two-pass moments of
+// <= 128 outputs per channel -> one partial per (row, box, wave, group), like the other forward kernels write them).
 struct FwdC1Geom {
     static constexpr int BX = 32, BY = 8, BZ = 4;
     static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
@@ -506,7 +506,7 @@ struct FwdC1Geom {
     static constexpr int NQ = (HV + 255) / 256;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_c1_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv3d_k3_fwd_c1_kernel(ConvArgs a) {
     using G = FwdC1Geom;
     constexpr int BY = G::BY, HX = G::HX, HY = G::HY, HV = G::HV, NQ = G::NQ;
     __shared__ float lx[HV + 8];
@@ -562,36 +562,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_c1_kernel(ConvArgs a) {
     const int gx = x0 + j, gz = z0 + wave;
     const bool okxz = gx < W && gz < D;
     const unsigned vbase = 4u * (unsigned)((gz * H + y0) * W + gx) + (unsigned)(co0 + 4 * kh) * S4;
-    float bias16[16];
     const bool has_bias = a.bias != nullptr;
-    if (has_bias) {
-        const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(a.bias, 4u * (unsigned)Cout);
+    // a channel tile that reaches past Cout: the register's channel is part of the scalar offset, which the descriptor's
+    // range check does not see -- those lanes get the out-of-range vector offset instead
+    const bool full_tile = co0 + 32 <= Cout;
+    unsigned cmask = 0xffffu;
+    if (!full_tile) {
+        cmask = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bias16[r] = buf_load(bsrd, 4u * (unsigned)(co0 + 4 * kh + (r & 3) + 8 * (r >> 2)), 0);
+        for (int r = 0; r < 16; ++r) cmask |= (co0 + 4 * kh + (r & 3) + 8 * (r >> 2) < Cout ? 1u : 0u) << r;
     }
 
-    f32x16 acc[BY];
+    // two groups of four rows: 64 accumulator registers live (three blocks per CU), one statistics partial per group
+    constexpr int NT = BY / 2;
 #pragma unroll
-    for (int t = 0; t < BY; ++t) {
+    for (int grp = 0; grp < 2; ++grp) {
+        f32x16 acc[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const int row = grp * NT + t;
 #pragma unroll
-        for (int s = 0; s < 14; ++s)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], lx[boff[s] + t * HX], acc[t], 0, 0, 0);
-        if (has_bias) {
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += bias16[r];
+            for (int s = 0; s < 14; ++s)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], lx[boff[s] + row * HX], acc[t], 0, 0, 0);
+            if (has_bias) {
+                const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(a.bias, 4u * (unsigned)Cout);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += buf_load(bsrd, 4u * (unsigned)(co0 + 4 * kh + (r & 3) + 8 * (r >> 2)), 0);
+            }
+            const unsigned voff = (okxz && (y0 + row) < H) ? vbase + 4u * (unsigned)(row * W) : OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float val = acc[t][r];    // (a copy: __builtin_bit_cast applied to the vector ELEMENT reads element 0 under hipcc 7.2)
+                const unsigned vo = full_tile ? voff : (((cmask >> r) & 1u) ? voff : OOB);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), dsrd, (int)vo,
+                                                      (int)((unsigned)((r & 3) + 8 * (r >> 2)) * S4), 0);
+            }
         }
-        const unsigned voff = (okxz && (y0 + t) < H) ? vbase + 4u * (unsigned)(t * W) : OOB;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[t][r]), dsrd, (int)voff,
-                                                  (int)((unsigned)((r & 3) + 8 * (r >> 2)) * S4), 0);
-    }
-    if (a.stats) {
-        const int pidx = (((bz * a.nby) + by) * a.nbx + bx) * 4 + wave;
-        stats_epilogue_tiles<BY>([&](int t, int i) { return acc[t][i]; }, [&](int t) { return okxz && (y0 + t) < H; }, lane, a.stats,
-                                 (int64_t)n * Cout, co0, Cout, a.nparts, pidx);
+        if (a.stats) {
+            const int pidx = ((((bz * a.nby) + by) * a.nbx + bx) * 4 + wave) * 2 + grp;
+            stats_epilogue_tiles<NT>([&](int t, int i) { return acc[t][i]; }, [&](int t) { return okxz && (y0 + grp * NT + t) < H; }, lane,
+                                     a.stats, (int64_t)n * Cout, co0, Cout, a.nparts, pidx);
+        }
     }
 }
 
@@ -2491,6 +2504,7 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
     c.c1 = !direct && a.Cin == 1 && a.src.p2 == nullptr && a.dst.p2 == nullptr && a.coef1 == nullptr;
     if (c.c1) {
         c.box = 0;
+        c.parts_per_box = 8;            // (wave, row group)
         c.nbx = cdiv(a.W, FwdC1Geom::BX); c.nby = cdiv(a.H, FwdC1Geom::BY); c.nbz = cdiv(a.D, FwdC1Geom::BZ);
         return c;
     }
