@@ -2262,6 +2262,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_c1_kernel(WgradC1Args 
     }
 }
 
+#include "wgrad_wzy.inc"
+
 static inline int wgrad_c1_blocks(int nboxes) { return nboxes < 1024 ? nboxes : 1024; }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t E, int split) {
@@ -2607,6 +2609,8 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
 struct WgradPlan {
     int variant;  // 0: block = 64 co x 32 ci (Cout <= 64);  1: block = 128 co x 16 ci
     int wz;       // 1: Winograd-z kernel (boxes = bx x by positions of a plane pair)
+    int wzy;      // 1: Winograd-(z,y) kernel (boxes = 16 x positions of a y pair and z pair); cit = 16-channel ci tiles per block
+    int cit;
     int bx, by, bz, nbx, nby, nbz, nboxes, ci_tiles, co_tiles, split;
 };
 
@@ -2614,6 +2618,42 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
     WgradPlan p;
     p.variant = Cout > 64 ? 1 : 0;
     p.wz = 0;
+    p.wzy = 0;
+    p.cit = 1;
+    {   // Winograd-(z,y): full 16-wide boxes along x, whole y and z pairs, a ci tile inside one source tensor
+        static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
+        const bool off = getenv("DRAM_WGRAD_NO_WZY") != nullptr;      // (read per call: A/B tests toggle it inside one process)
+        int cit = 1;
+        if (const char* f = getenv("DRAM_WGRAD_WZY_CIT")) cit = atoi(f) == 2 ? 2 : 1;          // experiments only
+        if (!direct && !off && W % 16 == 0 && H % 2 == 0 && D % 2 == 0 && (C1 == 0 || C1 % (16 * cit) == 0)) {
+            p.wzy = 1;
+            p.cit = cit;
+            p.bx = 16; p.by = 2; p.bz = 2;
+            p.nbx = W / 16; p.nby = H / 2; p.nbz = D / 2;
+            p.nboxes = (int)((int64_t)N * p.nbx * p.nby * p.nbz);
+            p.ci_tiles = cdiv(Cin, 16 * cit);
+            p.co_tiles = cdiv(Cout, 64);
+            // one 256-thread block per CU; contiguous box ranges, so the split only has to fill the device evenly
+            const int tiles = p.ci_tiles * p.co_tiles;
+            const int resident = 256;
+            const size_t slab = (size_t)Cout * Cin * 27 * sizeof(float);
+            int best = 1;
+            double best_score = -1.0;
+            for (int sp = 1; sp <= p.nboxes && sp <= 4096; ++sp) {
+                const int64_t blocks = (int64_t)tiles * sp;
+                if (blocks > 4LL * resident && sp > 1) break;
+                if ((size_t)sp * slab > ((size_t)1 << 30) && sp > 1) break;
+                const int64_t rounds = (blocks + resident - 1) / resident;
+                double util = (double)blocks / (double)(rounds * resident);
+                const int64_t per = (p.nboxes + sp - 1) / sp;
+                util *= (double)p.nboxes / (double)(per * sp);
+                const double score = util + 1e-3 * (blocks >= 2LL * resident ? 1.0 : (double)blocks / (2.0 * resident));
+                if (score > best_score) { best_score = score; best = sp; }
+            }
+            p.split = best;
+            return p;
+        }
+    }
     {   // Winograd-z: rows must be full boxes along x and a channel tile must lie inside one source tensor.  Its 64 co x
         // 32 ci tile (two LDS stages, one barrier per box) serves wide layers too: measured 197-200 TFLOP/s direct-equivalent
         // against 186-190 for the 128 co x 16 ci tile at 384->128, 256->256, 768->256; the latter remains for a concat
@@ -2693,6 +2733,22 @@ static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
     return (a.coef1 || a.coef2) ? launch_wgrad_wz_l<BX, BY, COS, CIT, true>(a, st) : launch_wgrad_wz_l<BX, BY, COS, CIT, false>(a, st);
 }
 
+template <int CIT, bool LAZY>
+static int launch_wgrad_wzy_l(WgradArgs& a, hipStream_t st) {
+    using G = WgradWzyGeom<CIT>;
+    static LdsAttrOnce lds_once;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wzy_kernel<CIT, LAZY>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad(wzy)")) return rc;
+    const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
+    const int per = cdiv(a.nboxes, a.split);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wzy_kernel<CIT, LAZY>), dim3(grid), dim3(256), G::LDS_BYTES, st, a, per);
+    return check_launch("conv3d_k3_wgrad(wzy)");
+}
+static int launch_wgrad_wzy(WgradArgs& a, int cit, hipStream_t st) {
+    const bool lazy = a.coef1 || a.coef2;
+    if (cit == 2) return lazy ? launch_wgrad_wzy_l<2, true>(a, st) : launch_wgrad_wzy_l<2, false>(a, st);
+    return lazy ? launch_wgrad_wzy_l<1, true>(a, st) : launch_wgrad_wzy_l<1, false>(a, st);
+}
+
 template <int BX, int BY, int BZ, int COS, int CIT>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
     using G = WgradGeom<BX, BY, BZ, COS, CIT>;
@@ -2715,6 +2771,12 @@ static WgradKernel wgrad_kernel(const WgradPlan& p, int C1, bool has_x2, int W, 
     k.cos = p.variant == 1 ? 8 : 4;
     k.cit = p.variant == 1 ? 1 : 2;
     k.lazy = false;
+    if (p.wzy) {
+        k.kind = DRAM_K3_WGRAD_WZY;
+        k.cit = p.cit;
+        k.lazy = lazy;
+        return k;
+    }
     if (p.wz) {
         k.kind = lazy ? DRAM_K3_WGRAD_WZ_LAZY : DRAM_K3_WGRAD_WZ;
         k.lazy = lazy;
@@ -2729,6 +2791,7 @@ static WgradKernel wgrad_kernel(const WgradPlan& p, int C1, bool has_x2, int W, 
 static void wgrad_kernel_name(const WgradKernel& k, char* name, size_t cap) {
     if (!name || !cap) return;
     if (k.kind == DRAM_K3_WGRAD_C1) snprintf(name, cap, "conv3d_k3_wgrad_c1_kernel");
+    else if (k.kind == DRAM_K3_WGRAD_WZY) snprintf(name, cap, "conv3d_k3_wgrad_wzy_kernel<%d, %s>", k.cit, k.lazy ? "true" : "false");
     else if (k.kind == DRAM_K3_WGRAD_WZ || k.kind == DRAM_K3_WGRAD_WZ_LAZY)
         snprintf(name, cap, "conv3d_k3_wgrad_wz_kernel<%d, %d, %d, %d, %s>", k.bx, k.by, k.cos, k.cit, k.lazy ? "true" : "false");
     else
@@ -2859,7 +2922,7 @@ extern "C" int dram_conv3d_k3_wgrad_choice(int N, int C1, int C2, int Cout, int 
         k.kind = DRAM_K3_WGRAD_C1;
     } else {
         const WgradPlan p = wgrad_plan(N, C1 + C2, Cout, D, H, W, C2 > 0 ? C1 : 0);
-        k = wgrad_kernel(p, C1, C2 > 0, W, lazy != 0 && p.wz);
+        k = wgrad_kernel(p, C1, C2 > 0, W, lazy != 0 && (p.wz || p.wzy));
     }
     wgrad_kernel_name(k, name, cap);
     return k.kind;
@@ -2921,7 +2984,8 @@ extern "C" size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D,
 extern "C" int dram_conv3d_k3_wgrad_lazy_ok(int N, int C1, int C2, int Cout, int D, int H, int W) {
     if (N <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (C1 + C2 == 1) return 0;
-    return wgrad_plan(N, C1 + C2, Cout, D, H, W, C2 > 0 ? C1 : 0).wz;
+    const WgradPlan p = wgrad_plan(N, C1 + C2, Cout, D, H, W, C2 > 0 ? C1 : 0);
+    return p.wz | p.wzy;
 }
 
 static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, const float* x2, int C2, const float* coef2,
@@ -2970,7 +3034,7 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
     DRAM_REQUIRE(((int64_t)(a.Cin > Cout ? a.Cin : Cout) + 128) * (int64_t)D * H * W < 0x3fffffffLL,
                  "conv3d_k3_wgrad: (channels + 128) * voxels per sample exceeds 2^30 (32-bit buffer offsets)");
     const WgradPlan p = wgrad_plan(N, a.Cin, Cout, D, H, W, x2 ? C1 : 0);
-    DRAM_REQUIRE(p.wz || (a.coef1 == nullptr && a.coef2 == nullptr),
+    DRAM_REQUIRE(p.wz || p.wzy || (a.coef1 == nullptr && a.coef2 == nullptr),
                  "conv3d_k3_wgrad_fused: this shape runs a kernel without the lazy-operand path "
                  "(dram_conv3d_k3_wgrad_lazy_ok): materialise x first");
     const size_t need = (size_t)p.split * Cout * a.Cin * 27 * sizeof(float);
@@ -2984,7 +3048,9 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
     const WgradKernel wk = wgrad_kernel(p, C1, x2 != nullptr, W, a.coef1 || a.coef2);
     g_launches[wk.kind].fetch_add(1, std::memory_order_relaxed);
     const bool vec = wk.kind == DRAM_K3_WGRAD_VEC;
-    if (p.wz) {
+    if (p.wzy) {
+        rc = launch_wgrad_wzy(a, p.cit, st);
+    } else if (p.wz) {
         if (p.variant == 1)
             rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : p.bx == 8 ? launch_wgrad_wz<8, 4, 8, 1>(a, st) : launch_wgrad_wz<4, 8, 8, 1>(a, st);
         else
