@@ -2623,8 +2623,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
     {   // Winograd-(z,y): full 16-wide boxes along x, whole y and z pairs, a ci tile inside one source tensor
         static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
         const bool off = getenv("DRAM_WGRAD_NO_WZY") != nullptr;      // (read per call: A/B tests toggle it inside one process)
-        int cit = 1;
-        if (const char* f = getenv("DRAM_WGRAD_WZY_CIT")) cit = atoi(f) == 2 ? 2 : 1;          // experiments only
+        const int cit = 1;
         if (!direct && !off && W % 16 == 0 && H % 2 == 0 && D % 2 == 0 && (C1 == 0 || C1 % (16 * cit) == 0)) {
             p.wzy = 1;
             p.cit = cit;
@@ -2733,20 +2732,18 @@ static int launch_wgrad_wz(WgradArgs& a, hipStream_t st) {
     return (a.coef1 || a.coef2) ? launch_wgrad_wz_l<BX, BY, COS, CIT, true>(a, st) : launch_wgrad_wz_l<BX, BY, COS, CIT, false>(a, st);
 }
 
-template <int CIT, bool LAZY>
+template <bool LAZY>
 static int launch_wgrad_wzy_l(WgradArgs& a, hipStream_t st) {
-    using G = WgradWzyGeom<CIT>;
+    using G = WgradWzyGeom;
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wzy_kernel<CIT, LAZY>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad(wzy)")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wzy_kernel<LAZY>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad(wzy)")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     const int per = cdiv(a.nboxes, a.split);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_wzy_kernel<CIT, LAZY>), dim3(grid), dim3(256), G::LDS_BYTES, st, a, per);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wzy_kernel<LAZY>), dim3(grid), dim3(256), G::LDS_BYTES, st, a, per);
     return check_launch("conv3d_k3_wgrad(wzy)");
 }
-static int launch_wgrad_wzy(WgradArgs& a, int cit, hipStream_t st) {
-    const bool lazy = a.coef1 || a.coef2;
-    if (cit == 2) return lazy ? launch_wgrad_wzy_l<2, true>(a, st) : launch_wgrad_wzy_l<2, false>(a, st);
-    return lazy ? launch_wgrad_wzy_l<1, true>(a, st) : launch_wgrad_wzy_l<1, false>(a, st);
+static int launch_wgrad_wzy(WgradArgs& a, hipStream_t st) {
+    return (a.coef1 || a.coef2) ? launch_wgrad_wzy_l<true>(a, st) : launch_wgrad_wzy_l<false>(a, st);
 }
 
 template <int BX, int BY, int BZ, int COS, int CIT>
@@ -2791,7 +2788,7 @@ static WgradKernel wgrad_kernel(const WgradPlan& p, int C1, bool has_x2, int W, 
 static void wgrad_kernel_name(const WgradKernel& k, char* name, size_t cap) {
     if (!name || !cap) return;
     if (k.kind == DRAM_K3_WGRAD_C1) snprintf(name, cap, "conv3d_k3_wgrad_c1_kernel");
-    else if (k.kind == DRAM_K3_WGRAD_WZY) snprintf(name, cap, "conv3d_k3_wgrad_wzy_kernel<%d, %s>", k.cit, k.lazy ? "true" : "false");
+    else if (k.kind == DRAM_K3_WGRAD_WZY) snprintf(name, cap, "conv3d_k3_wgrad_wzy_kernel<%s>", k.lazy ? "true" : "false");
     else if (k.kind == DRAM_K3_WGRAD_WZ || k.kind == DRAM_K3_WGRAD_WZ_LAZY)
         snprintf(name, cap, "conv3d_k3_wgrad_wz_kernel<%d, %d, %d, %d, %s>", k.bx, k.by, k.cos, k.cit, k.lazy ? "true" : "false");
     else
@@ -3049,7 +3046,7 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
     g_launches[wk.kind].fetch_add(1, std::memory_order_relaxed);
     const bool vec = wk.kind == DRAM_K3_WGRAD_VEC;
     if (p.wzy) {
-        rc = launch_wgrad_wzy(a, p.cit, st);
+        rc = launch_wgrad_wzy(a, st);
     } else if (p.wz) {
         if (p.variant == 1)
             rc = p.bx == 16 ? launch_wgrad_wz<16, 2, 8, 1>(a, st) : p.bx == 8 ? launch_wgrad_wz<8, 4, 8, 1>(a, st) : launch_wgrad_wz<4, 8, 8, 1>(a, st);
