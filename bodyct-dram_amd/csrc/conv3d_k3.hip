@@ -2624,7 +2624,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
         static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
         const bool off = getenv("DRAM_WGRAD_NO_WZY") != nullptr;      // (read per call: A/B tests toggle it inside one process)
         const int cit = 1;
-        if (!direct && !off && W % 16 == 0 && H % 2 == 0 && D % 2 == 0 && (C1 == 0 || C1 % (16 * cit) == 0)) {
+        if (!direct && !off && W % 16 == 0 && H % 2 == 0 && D % 2 == 0 && D >= 4 && (C1 == 0 || C1 % (16 * cit) == 0)) {   // (D >= 4: two boxes per z column, the raw plane ring counts on it)
             p.wzy = 1;
             p.cit = cit;
             p.bx = 16; p.by = 2; p.bz = 2;
