@@ -27,8 +27,8 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
         out = (ctypes.c_ulonglong * 8)()
         lib.dram_debug_wgrad_stamps(out, 0)
         nbox = max(out[7], 1)
-        names = ["slots 0-4 (20 MFMAs + prologue + fetch)", "slots 5-7 (12 MFMAs)", "slots 8-23 (64 MFMAs + transform)",
-                 "slots 24-47 (92 MFMAs)", "fetch wait", "barrier"]
+        names = ["MFMAs 0-47 (+ prologue, fetch)", "48-95 (+ fetch of column starts)", "96-143 (+ transform)",
+                 "144-187 (+ transform of the remainder patches)", "fetch wait", "barrier"]
         per = [out[t] / nbox for t in range(6)]
         print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and box {sum(per):.0f} (188 MFMAs = 6016 of matrix pipe): " +
               ", ".join(f"{names[t]} {per[t]:.0f}" for t in range(6)), flush=True)
