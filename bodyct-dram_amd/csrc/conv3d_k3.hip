@@ -2739,7 +2739,7 @@ static int launch_wgrad_wzy_l(WgradArgs& a, hipStream_t st) {
     if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_wgrad_wzy_kernel<LAZY>, G::LDS_BYTES, lds_once, "conv3d_k3_wgrad(wzy)")) return rc;
     const unsigned grid = (unsigned)(a.split * a.ci_tiles * a.co_tiles);
     const int per = cdiv(a.nboxes, a.split);
-    hipLaunchKernelGGL((conv3d_k3_wgrad_wzy_kernel<LAZY>), dim3(grid), dim3(256), G::LDS_BYTES, st, a, per);
+    hipLaunchKernelGGL((conv3d_k3_wgrad_wzy_kernel<LAZY>), dim3(grid), dim3(512), G::LDS_BYTES, st, a, per);
     return check_launch("conv3d_k3_wgrad(wzy)");
 }
 static int launch_wgrad_wzy(WgradArgs& a, hipStream_t st) {

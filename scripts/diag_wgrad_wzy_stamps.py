@@ -27,8 +27,7 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
         out = (ctypes.c_ulonglong * 8)()
         lib.dram_debug_wgrad_stamps(out, 0)
         nbox = max(out[7], 1)
-        names = ["MFMAs 0-47 (+ prologue, fetch)", "48-95 (+ fetch of column starts)", "96-143 (+ transform)",
-                 "144-187 (+ transform of the remainder patches)", "fetch wait", "barrier"]
-        per = [out[t] / nbox for t in range(6)]
-        print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and box {sum(per):.0f} (188 MFMAs = 6016 of matrix pipe): " +
-              ", ".join(f"{names[t]} {per[t]:.0f}" for t in range(6)), flush=True)
+        names = ["groups 0-11 (+ prologue, fetch)", "12-35 (+ transform)", "36-47", "fetch wait", "barrier"]
+        per = [out[t] / nbox for t in range(5)]
+        print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and box {sum(per):.0f} (96 MFMAs = 3072 of matrix pipe per wave, two waves per SIMD): " +
+              ", ".join(f"{names[t]} {per[t]:.0f}" for t in range(5)), flush=True)
