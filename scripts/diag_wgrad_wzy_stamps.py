@@ -26,8 +26,8 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
             torch.cuda.synchronize()
         out = (ctypes.c_ulonglong * 8)()
         lib.dram_debug_wgrad_stamps(out, 0)
-        nbox = max(out[7], 1)
-        names = ["groups 0-11 (+ prologue, fetch)", "12-35 (+ transform)", "36-47", "fetch wait", "barrier"]
-        per = [out[t] / nbox for t in range(5)]
-        print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and box {sum(per):.0f} (96 MFMAs = 3072 of matrix pipe per wave, two waves per SIMD): " +
-              ", ".join(f"{names[t]} {per[t]:.0f}" for t in range(5)), flush=True)
+        for half, who in ((0, "waves 0-3 (transform)"), (1, "waves 4-7 (fetch)")):
+            o = out[4 * half:4 * half + 4]
+            nbox = max(o[3], 1)
+            print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s} {who}: cycles per wave and box: MFMAs + rides {o[0] / nbox:.0f}, fetch wait {o[1] / nbox:.0f}, "
+                  f"barrier {o[2] / nbox:.0f}  (sum {sum(o[:3]) / nbox:.0f}; the SIMD pair's MFMAs: 6144)", flush=True)
