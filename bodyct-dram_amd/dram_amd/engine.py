@@ -324,9 +324,12 @@ LAST_PLAN = None        # (diagnostics only, never read by the engine) the plan 
 MAX_PLANES = 65535      # (n, c) planes per launch of the row / plane kernels (norm, pool, resize: planes ride on grid.y)
 
 
-def forward(model, x, record):
-    """DC3D.forward (models.py:120-147) on lazy tensors.  `record`: list that receives the tape for backward, or None
-    (inference).  Returns the dense output [N, out_ch, D, H, W]."""
+def forward(model, x, record, taps=()):
+    """DC3D.forward (models.py:120-147) / the backbone of DC3DATGeneric.forward (models.py:543-590) on lazy tensors.
+    `record`: list that receives the tape for backward, or None (inference).  `taps`: layer ids (0 .. n_layers-1: the skip
+    feature of that ConvPoolBlock5d, n_layers: the bottleneck output, n_layers+1+i: the output of up-block i) whose
+    activated feature maps are written out as well -- DC3DATGeneric feeds them, detached, to its attention module
+    (models.py:556,566,578).  Returns (dense output [N, out_ch, D, H, W], {layer id: feature map})."""
     global LAST_PLAN
     training = model.training
     plan = LAST_PLAN = _memory_plan(model, x, record is not None)
@@ -339,6 +342,10 @@ def forward(model, x, record):
                          f"{MAX_PLANES} a kernel launch addresses: run micro-batches of at most {MAX_PLANES // widest} chunks "
                          f"(DataParallelTrainer.step(batch, micro_batch=...))")
     grad_flows = record is not None          # the reference re-runs a checkpointed block in backward only then
+    taps = set(taps)
+    tapped = {}
+    # DC3D indexes the checkpoint flag of up-block i with n_layers + i, DC3DATGeneric with n_layers + 1 + i (models.py:140,573)
+    us_flag = L + int(getattr(model, "us_flag_offset", 0))
     cur = Lazy(x)
     if record is not None:
         record.append(("input", cur, plan))
@@ -360,8 +367,12 @@ def forward(model, x, record):
     for i, ds in enumerate(model.ds_modules):
         feat = run_block(model.checkpoint_layers[i], ds, lambda: _conv_stack(ds.conv_blocks, cur, None, training, record, plan))
         skips.append(feat)
+        if i in taps:
+            tapped[i] = feat.materialise()
         cur = _pool(feat, record)
     cur = run_block(model.checkpoint_layers[L], model.bg, lambda: _conv_stack(model.bg.conv_blocks, cur, None, training, record, plan))
+    if L in taps:
+        tapped[L] = cur.materialise()
     if model.us_modules is not None:
         for i, (us, skip) in enumerate(zip(model.us_modules, reversed(skips))):
             if model.stacking == i:
@@ -374,8 +385,9 @@ def forward(model, x, record):
             up = Upsampled(cur, size)
             if record is not None:
                 record.append(("up", cur, size))
-            # NB: the flag index is n_layers + idx, not n_layers + 1 + idx (models.py:140)
-            cur = run_block(model.checkpoint_layers[L + i], us, lambda: _conv_stack(us.conv_blocks, up, skip, training, record, plan))
+            cur = run_block(model.checkpoint_layers[us_flag + i], us, lambda: _conv_stack(us.conv_blocks, up, skip, training, record, plan))
+            if L + 1 + i in taps:
+                tapped[L + 1 + i] = cur.materialise()
     top = model.top_layer
     N, C, D, H, W = cur.raw.shape
     Co = top.weight.shape[0]
@@ -390,7 +402,7 @@ def forward(model, x, record):
         call("dram_upsample_trilinear_ac_fwd", _p(small), _p(dense), N, Co, D, H, W, *x.shape[-3:], _stream())
         if record is not None:
             record.append(("resize", tuple(small.shape)))
-    return dense
+    return dense, tapped
 
 
 # ------------------------------------------------------------------------------------------------ backward
@@ -558,35 +570,49 @@ def _accumulate(gact, key, t):
 
 # ------------------------------------------------------------------------------------------------ autograd wrapper
 class DC3DFusedFn(Function):
-    """dense = DC3D(x) through the fused engine; differentiable w.r.t. x and every parameter."""
+    """(dense, *tapped feature maps) = DC3D(x) through the fused engine; `dense` is differentiable w.r.t. x and every
+    parameter, the tapped maps are outputs without a gradient (the reference detaches them, models.py:556,566,578)."""
 
     @staticmethod
-    def forward(ctx, model, x, *params):
+    def forward(ctx, model, taps, x, *params):
         # (torch runs Function.forward under no_grad: whether a gradient is wanted comes from needs_input_grad)
-        record = [] if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[2:]) else None
-        out = forward(model, x, record)
+        record = [] if ctx.needs_input_grad[2] or any(ctx.needs_input_grad[3:]) else None
+        out, tapped = forward(model, x, record, taps)
         ctx.model, ctx.record, ctx.params = model, record, params
-        return out
+        extra = tuple(tapped[t] for t in taps)
+        ctx.mark_non_differentiable(*extra)
+        return (out,) + extra
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gout):
+    def backward(ctx, gout, *_):
         model, record, params = ctx.model, ctx.record, ctx.params
         if record is None:
             raise RuntimeError("DC3DFusedFn: backward without a recorded forward")
         try:
-            grads, dx = backward(model, record, gout, ctx.needs_input_grad[1])
+            grads, dx = backward(model, record, gout, ctx.needs_input_grad[2])
         finally:
             ctx.record = None        # free the saved activations now, not when the graph dies
-        out = [None, dx if ctx.needs_input_grad[1] else None]
-        for p, need in zip(params, ctx.needs_input_grad[2:]):
+        out = [None, None, dx if ctx.needs_input_grad[2] else None]
+        for p, need in zip(params, ctx.needs_input_grad[3:]):
             out.append(grads.get(p) if need else None)
         return tuple(out)
 
 
-def run(model, x):
-    """DC3D forward through the engine (autograd-connected when gradients are enabled)."""
-    params = parameters_of(model)
+def backbone_parameters(model):
+    """The parameters of the U-Net proper (DC3DATGeneric carries more: its reshape convs and attention module run outside)."""
+    mods = list(model.ds_modules) + [model.bg] + list(model.us_modules or []) + [model.top_layer]
+    return [p for m in mods for p in m.parameters()]
+
+
+def run(model, x, taps=()):
+    """DC3D forward through the engine (autograd-connected when gradients are enabled).  Returns the dense output, or
+    (dense, {layer id: feature map}) when `taps` are asked for."""
+    taps = tuple(taps)
+    params = backbone_parameters(model)
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        return DC3DFusedFn.apply(model, x, *params)
-    return forward(model, x, None)
+        res = DC3DFusedFn.apply(model, taps, x, *params)
+        dense, tapped = res[0], dict(zip(taps, res[1:]))
+    else:
+        dense, tapped = forward(model, x, None, taps)
+    return (dense, tapped) if taps else dense

@@ -414,6 +414,11 @@ class DC3DATGeneric(nn.Module):
         return pooling_dense_features(dense_outs, lungs, pooling_method)
 
     _run = DC3D._run
+    us_flag_offset = 1              # checkpoint flag of up-block i: n_layers + 1 + i (models.py:573; DC3D: n_layers + i)
+    # `fused` (default): the U-Net proper runs through dram_amd/engine.py like DC3D (one autograd node, norm statistics in the
+    # conv epilogue, normalise + ReLU on load), the engine writes out the feature maps the attention module taps, and the
+    # reshape convs, resizes and PCM run on their own kernels behind it.
+    fused = True
 
     def apply_attention(self, x, lungs, dense_out, attention_features):
         """models.py:498-506: resize the dense map to the attention grid, refine, resize back."""
@@ -430,6 +435,18 @@ class DC3DATGeneric(nn.Module):
             feats.append(run_conv_stack([self.reshape[nc]], t.detach()))
             nc += 1
 
+        if self.fused and self.checkpoint_mode != "recompute" and _engine.supports(self):
+            n_up = self.stacking if 0 <= self.stacking < len(self.us_modules) else len(self.us_modules)   # (the loop below breaks at `stacking`)
+            ids = [l for l in range(L + 1 + n_up) if l in self.at_layers]
+            res = _engine.run(self, x, taps=ids)
+            top, tapped = res if ids else (res, {})
+            for l in ids:           # ascending layer id = the order in which the reference's forward meets them
+                tap(tapped[l])
+            dense_outs = top
+            feats = [_resize(t, self.at_spatial_size) for t in feats]
+            attention_features = functools.reduce(HF.crop_concat, feats)
+            refined_dense_outs = self.apply_attention(x, lungs, dense_outs, attention_features)
+            return dense_outs, refined_dense_outs
         skips = []
         cur = x
         for idx, ds in enumerate(self.ds_modules):

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--size", type=int, default=80)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-fused", action="store_true", help="the per-op path instead of the fused engine")
     a = ap.parse_args()
     import models
     from dram_amd.train_step import DataParallelTrainer, synthetic_batch
@@ -31,6 +32,7 @@ def main():
     m = models.DC3DATGeneric(**cfg)
     m.init(models.HeNorm(mode="fan_in"))
     m = m.cuda().train()
+    m.fused = not a.no_fused
     tr = DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=1e-4))
     batch = synthetic_batch(a.n, a.size, 100, torch.device("cuda"))
     tr.step(batch)
@@ -52,7 +54,7 @@ def main():
         att(cam, f).sum().backward()
     torch.cuda.synchronize()
     dpcm = (time.perf_counter() - t0) / 10
-    print({"model": "DC3DATGeneric(st_dram_ref_att)", "chunks": a.n, "size": a.size, "ms_per_step": dt * 1e3,
+    print({"model": "DC3DATGeneric(st_dram_ref_att)", "fused_engine": bool(m.fused), "peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "chunks": a.n, "size": a.size, "ms_per_step": dt * 1e3,
            "voxels_per_s": a.n * a.size ** 3 / dt, "pcm_fwd_bwd_ms": dpcm * 1e3, "reg": float(reg), "seg": float(seg)})
 
 

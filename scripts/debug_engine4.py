@@ -40,7 +40,7 @@ for h in hooks: h.remove()
 ref = {k: p.grad.clone() for k, p in model.named_parameters()}
 for p in model.parameters(): p.grad = None
 record = []
-out = engine.forward(model, x, record)
+out, _ = engine.forward(model, x, record)
 stages = [it[1] for it in record if it[0] == "conv"]
 ymap = {s.y.data_ptr(): nm for s, nm in zip(stages, names)}
 real_call = E.call

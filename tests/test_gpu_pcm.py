@@ -292,3 +292,38 @@ def test_trainer_step_dc3dat(golden_dir):
     assert torch.isfinite(reg) and torch.isfinite(seg)
     moved = [k for k, v in m.named_parameters() if not torch.equal(v, before[k])]
     assert any(k.startswith("attention_module.") for k in moved) and any(k.startswith("ds_modules.0") for k in moved)
+
+
+def test_dc3dat_runs_on_the_fused_engine_and_equals_the_per_op_path(golden_dir):
+    """DC3DATGeneric's U-Net goes through dram_amd/engine.py (one autograd node; the tapped feature maps come out of it
+    detached, reference models.py:556,566,578) and gives the step of the per-op path: both outputs, every gradient, the
+    BatchNorm buffers (flagged blocks updated twice, with DC3DATGeneric's flag index n_layers + 1 + idx, models.py:573)."""
+    from dram_amd import engine
+    res = {}
+    for fused in (False, True):
+        z, tag, sd, m = _load_att(golden_dir)
+        with torch.no_grad():       # pre-activations away from the ReLU threshold (see tests/test_gpu_engine.py)
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm3d):
+                    sign = torch.where(torch.arange(mod.bias.numel()) % 3 == 2, -1.0, 1.0)
+                    mod.bias.copy_(3.0 * sign * mod.weight.abs().clamp_min(0.1))
+        m = m.cuda().train()
+        m.fused = fused
+        assert engine.supports(m)
+        x = torch.from_numpy(z[tag + "/x"]).cuda()
+        d0, d1 = m(x, None)
+        assert (type(d0.grad_fn).__name__ == "DC3DFusedFnBackward") == fused
+        t = lambda k: torch.from_numpy(z[tag + k]).cuda()
+        ((d0 * t("/gout0").abs()).sum() + (d1 * t("/gout1").abs()).sum()).backward()
+        res[fused] = (d0.detach(), d1.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                      {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b = res[False], res[True]
+    assert rel(b[0], a[0]) <= 2e-5 and rel(b[1], a[1]) <= 2e-5
+    assert set(a[2]) == set(b[2])
+    gmax = max(float(v.abs().max()) for v in a[2].values())
+    for k in a[2]:
+        if k.startswith("reshape.") and k.endswith(".0.bias"):
+            continue            # a conv bias in front of BatchNorm: exactly zero in theory, rounding noise on both sides
+        assert rel(b[2][k], a[2][k]) <= 1e-4 or float((b[2][k] - a[2][k]).abs().max()) <= 1e-6 * gmax, k
+    for k in a[3]:
+        assert rel(b[3][k].double(), a[3][k].double()) <= 1e-5, k
