@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-att", action="store_true", help="skip the attention-model step reported beside the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to rehearse the multi-rank path with several ranks on one GPU)")
     return ap.parse_args()
@@ -147,6 +148,29 @@ def cpu_baseline(budget_s):
             "value_2x64": v64,
             "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd on {threads} threads: 1x1x128^3 median of {r128} "
                       f"rep(s) (value); 2x1x64^3 median of {r64} reps after 1 warm-up (value_2x64)"}
+
+
+def att_model_step(dev, n=10, size=80, steps=3):
+    import torch
+    import models
+    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL
+    from dram_amd.train_step import DataParallelTrainer, synthetic_batch
+    torch.manual_seed(0)
+    m = models.DC3DATGeneric(**ST_DRAM_REF_ATT_MODEL)
+    m.init(models.HeNorm(mode="fan_in"))
+    m = m.to(dev).train()
+    tr = DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=1e-4))
+    b = synthetic_batch(n, size, 100, dev)
+    tr.step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        reg, seg = tr.step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"model": "DC3DATGeneric st_dram_ref_att (attention grid 64^3, 18 neighbours)", "chunks": n, "chunk": [size] * 3,
+            "ms_per_step": 1e3 * dt, "voxels_per_s": n * size ** 3 / dt, "fused_engine": bool(m.fused),
+            "reg": float(reg), "seg": float(seg)}
 
 
 def launch_ranks(n):
@@ -346,6 +370,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)
 
+    # ---- outside the timed region and not part of `value`: the attention model that process_pipeline.py loads
+    # (DC3DATGeneric(st_dram_ref_att), reference models.py:415-597) at the reference's own training shape -- TRAIN_BATCH_SIZE 10
+    # chunks of RESAMPLE_SIZE 80^3 (st_dram_ref_att.py:40-45) -- through the same engine and trainer
+    att = None
+    ck_mode = model.checkpoint_mode
+    if rank == 0 and world == 1 and not args.no_att:
+        del trainer, opt, model, batch, losses
+        torch.cuda.empty_cache()
+        att = att_model_step(dev)
+
     if rank == 0:
         flops_per_voxel = 5415936.0     # fwd+bwd algorithmic FLOPs per input voxel
         tot_alg = sum(d["flops"] for d in summ.values())
@@ -358,7 +392,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DC3D st_dram_ref (norm={args.norm}, checkpoint_layers as shipped, honoured as "
-                                   f"'{model.checkpoint_mode}') "
+                                   f"'{ck_mode}') "
                                    f"fwd+loss+bwd+Adam, {args.chunks}x1x{args.size}^3 chunks per GPU, "
                                    f"micro-batch {args.micro}, fp32",
                        "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,
@@ -376,6 +410,7 @@ def main():
             "loss": {"reg": [l[0] for l in loss_hist], "seg": [l[1] for l in loss_hist],
                      "param_abs_sum_after": psum, "finite": finite},
             "dist": dist_info,
+            "attention_model_step": att,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)

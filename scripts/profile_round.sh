@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 mkdir -p "$O"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- \
-    python3 bench.py --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/kt.err"
+    python3 bench.py --no-cpu-baseline --no-att > "$O/bench_under_rocprof.json" 2> "$O/kt.err"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- \
-    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > "$O/f.out" 2> "$O/f.err"
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-att --no-kernel-timer > "$O/f.out" 2> "$O/f.err"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- \
-    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > "$O/w.out" 2> "$O/w.err"
+    python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-att --no-kernel-timer > "$O/w.out" 2> "$O/w.err"
 find "$O" -name "*kernel_trace.csv" -delete     # per-dispatch trace: large, the stats CSV is what is kept
 find "$O" -name "*.csv" | xargs ls -la

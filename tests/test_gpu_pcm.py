@@ -318,12 +318,13 @@ def test_dc3dat_runs_on_the_fused_engine_and_equals_the_per_op_path(golden_dir):
         res[fused] = (d0.detach(), d1.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
                       {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
     a, b = res[False], res[True]
+    a = (a[0].cpu(), a[1].cpu(), {k: v.cpu() for k, v in a[2].items()}, {k: v.cpu() for k, v in a[3].items()})
     assert rel(b[0], a[0]) <= 2e-5 and rel(b[1], a[1]) <= 2e-5
     assert set(a[2]) == set(b[2])
     gmax = max(float(v.abs().max()) for v in a[2].values())
     for k in a[2]:
         if k.startswith("reshape.") and k.endswith(".0.bias"):
             continue            # a conv bias in front of BatchNorm: exactly zero in theory, rounding noise on both sides
-        assert rel(b[2][k], a[2][k]) <= 1e-4 or float((b[2][k] - a[2][k]).abs().max()) <= 1e-6 * gmax, k
+        assert rel(b[2][k], a[2][k]) <= 1e-4 or float((b[2][k].cpu() - a[2][k]).abs().max()) <= 1e-6 * gmax, k
     for k in a[3]:
         assert rel(b[3][k].double(), a[3][k].double()) <= 1e-5, k
