@@ -261,6 +261,12 @@ __device__ __forceinline__ void stats_epilogue_tiles(YF Y, OKF OK, int lane, flo
     }
 }
 
+template <typename YF>
+__device__ __forceinline__ void stats_epilogue_tiles4(YF Y, bool ok, int lane, float* __restrict__ stats, int64_t row0, int co0, int Cout,
+                                                      int nparts, int pidx) {
+    stats_epilogue_tiles<4>(Y, [&](int) { return ok; }, lane, stats, row0, co0, Cout, nparts, pidx);
+}
+
 // Operand transform of a lazily normalised source (ConvArgs::coef1/2): per K-chunk channel the wave-uniform
 // {a, b, lo}: v -> max(a*v + b, lo), lo = 0 with ReLU and -inf without; identity {1, 0, -inf} for a plain source,
 // {0, 0, 0} for the channel tail beyond Cin.
@@ -604,6 +610,120 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3_fwd_c1_kernel(ConvArgs a) {
             const int pidx = ((((bz * a.nby) + by) * a.nbx + bx) * 4 + wave) * 2 + grp;
             stats_epilogue_tiles<NT>([&](int t, int i) { return acc[t][i]; }, [&](int t) { return okxz && (y0 + grp * NT + t) < H; }, lane,
                                      a.stats, (int64_t)n * Cout, co0, Cout, a.nparts, pidx);
+        }
+    }
+}
+
+// The same for wide volumes (W % 4 == 0, W >= 96): a lane owns FOUR consecutive x of a row -- tile tt of a row holds x = 4 j + tt
+// -- so that a channel's 128-wide row leaves as 32 lanes x 16 bytes = 512 contiguous bytes per store instruction (four times
+// fewer store instructions; the 32-wide form writes 128-byte pieces).  Block = 128 x 4 x 4 voxels, wave = one z plane, a row =
+// four tiles = 64 accumulator registers with its own statistics partial.  B operands are LDS reads at stride 4 (2-way bank
+// conflicts: 14 reads against 14 x 64 cycles of MFMA per tile).
+struct FwdC1WGeom {
+    static constexpr int BX = 128, BY = 4, BZ = 4;
+    static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    static constexpr int HV = HX * HY * HZ;     // 4680
+    static constexpr int NQ = (HV + 255) / 256;
+};
+
+__global__ __launch_bounds__(256, 3) void conv3d_k3_fwd_c1w_kernel(ConvArgs a) {
+    using G = FwdC1WGeom;
+    constexpr int BY = G::BY, HX = G::HX, HY = G::HY, HV = G::HV, NQ = G::NQ;
+    __shared__ float lx[HV + 8];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    int b = xcd_remap(blockIdx.x, gridDim.x);       // logical item = (box, co tile), co tile fastest
+    const int co0 = (b % a.co_tiles) * 32; b /= a.co_tiles;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    const int n = b / a.nbz;
+    const int x0 = bx * G::BX, y0 = by * G::BY, z0 = bz * G::BZ;
+    const int D = a.D, H = a.H, W = a.W, Cout = a.Cout;
+    const int S = D * H * W;
+
+    {   // input halo -> LDS (zero padding by the descriptor's range check)
+        const __amdgpu_buffer_rsrc_t srx = make_rsrc(uniform_ptr(a.src.p1 + (size_t)n * S), 4u * (unsigned)S);
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += 5) {
+            float v[5];
+#pragma unroll
+            for (int q = q0; q < q0 + 5 && q < NQ; ++q) {
+                const int e = tid + 256 * q;
+                const int hx = e % HX, hy = (e / HX) % HY, hz = e / (HX * HY);
+                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                const int ok = (int)(e < HV) & (int)((unsigned)gx < (unsigned)W) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gz < (unsigned)D);
+                v[q - q0] = buf_load(srx, ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB, 0);
+            }
+#pragma unroll
+            for (int q = q0; q < q0 + 5 && q < NQ; ++q)
+                if (tid + 256 * q < HV) lx[tid + 256 * q] = v[q - q0];
+        }
+    }
+    float wa[14];
+    int boff[14];
+    {
+        const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 27u * 4u * (unsigned)Cout);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int tap = 2 * s + kh;
+            const int ok = (int)(tap < 27) & (int)(co0 + j < Cout);
+            wa[s] = buf_load(wsrd, ok ? 4u * (unsigned)(tap * Cout + co0 + j) : OOB, 0);
+            const int tp = tap < 27 ? tap : 0;
+            boff[s] = ((tp / 9 + wave) * HY + (tp / 3) % 3) * HX + tp % 3 + 4 * j;
+        }
+    }
+    __syncthreads();
+
+    const unsigned S4 = 4u * (unsigned)S;
+    const __amdgpu_buffer_rsrc_t dsrd = make_rsrc(uniform_ptr(a.dst.p1 + (size_t)n * Cout * S), (unsigned)Cout * S4);
+    const int gx = x0 + 4 * j, gz = z0 + wave;
+    const bool okxz = gx < W && gz < D;             // (W % 4 == 0: a lane's four x are inside together)
+    const unsigned vbase = 4u * (unsigned)((gz * H + y0) * W + gx) + (unsigned)(co0 + 4 * kh) * S4;
+    const bool has_bias = a.bias != nullptr;
+    const bool full_tile = co0 + 32 <= Cout;
+    unsigned cmask = 0xffffu;
+    if (!full_tile) {
+        cmask = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cmask |= (co0 + 4 * kh + (r & 3) + 8 * (r >> 2) < Cout ? 1u : 0u) << r;
+    }
+#pragma unroll
+    for (int row = 0; row < BY; ++row) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s)
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], lx[boff[s] + row * HX + tt], acc[tt], 0, 0, 0);
+        }
+        if (has_bias) {
+            const __amdgpu_buffer_rsrc_t bsrd = make_rsrc(a.bias, 4u * (unsigned)Cout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bb = buf_load(bsrd, 4u * (unsigned)(co0 + 4 * kh + (r & 3) + 8 * (r >> 2)), 0);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[tt][r] += bb;
+            }
+        }
+        const unsigned voff = (okxz && (y0 + row) < H) ? vbase + 4u * (unsigned)(row * W) : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+            const float v0 = acc[0][r], v1 = acc[1][r], v2 = acc[2][r], v3 = acc[3][r];
+            const u32x4s pk = {__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), __builtin_bit_cast(unsigned, v2),
+                               __builtin_bit_cast(unsigned, v3)};
+            const unsigned vo = full_tile ? voff : (((cmask >> r) & 1u) ? voff : OOB);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, dsrd, (int)vo, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * S4), 0);
+        }
+        if (a.stats) {
+            const int pidx = ((((bz * a.nby) + by) * a.nbx + bx) * 4 + wave) * BY + row;
+            stats_epilogue_tiles4([&](int t, int i) { return acc[t][i]; }, okxz && (y0 + row) < H, lane, a.stats, (int64_t)n * Cout, co0,
+                                  Cout, a.nparts, pidx);
         }
     }
 }
@@ -2491,6 +2611,7 @@ static bool use_wzy(const ConvArgs& a) {
 
 struct FwdChoice {
     bool c1;            // first-layer kernel (Cin = 1, plain source and destination)
+    bool c1w;           // ... its wide form (a lane owns four consecutive x: W % 4 == 0, W >= 96)
     bool wz;
     bool wzy;
     int box;            // index into the kernel family's box table
@@ -2504,6 +2625,13 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
     c.parts_per_box = 4;
     static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
     c.c1 = !direct && a.Cin == 1 && a.src.p2 == nullptr && a.dst.p2 == nullptr && a.coef1 == nullptr;
+    c.c1w = c.c1 && a.W % 4 == 0 && a.W >= 96 && getenv("DRAM_C1_NARROW") == nullptr;
+    if (c.c1w) {
+        c.box = 0;
+        c.parts_per_box = 16;           // (wave, row)
+        c.nbx = cdiv(a.W, FwdC1WGeom::BX); c.nby = cdiv(a.H, FwdC1WGeom::BY); c.nbz = cdiv(a.D, FwdC1WGeom::BZ);
+        return c;
+    }
     if (c.c1) {
         c.box = 0;
         c.parts_per_box = 8;            // (wave, row group)
@@ -2551,7 +2679,7 @@ static int fwd_kernel_id(const ConvArgs& a, const FwdChoice& c, char* name, size
     char buf[96];
     if (c.c1) {
         kind = DRAM_K3_FWD_C1;
-        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_c1_kernel");
+        snprintf(buf, sizeof(buf), c.c1w ? "conv3d_k3_fwd_c1w_kernel" : "conv3d_k3_fwd_c1_kernel");
     } else if (c.wzy) {
         kind = DRAM_K3_FWD_WZY;
         snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wzy_kernel");
@@ -2583,7 +2711,8 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
             set_error("conv3d_k3_fwd: grid too large");
             return DRAM_EINVAL;
         }
-        hipLaunchKernelGGL(conv3d_k3_fwd_c1_kernel, dim3((unsigned)total), dim3(256), 0, st, a);
+        if (c.c1w) hipLaunchKernelGGL(conv3d_k3_fwd_c1w_kernel, dim3((unsigned)total), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(conv3d_k3_fwd_c1_kernel, dim3((unsigned)total), dim3(256), 0, st, a);
         return check_launch("conv3d_k3_fwd(c1)");
     }
     if (c.wzy) {

@@ -8,7 +8,7 @@ from dram_amd import _lib
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 p = lambda t: None if t is None else t.data_ptr()
-for N, Co, D, H, W, bias in ((1, 32, 4, 8, 32, False), (2, 32, 5, 9, 33, False), (1, 40, 8, 16, 64, True), (3, 8, 6, 7, 10, False)):
+for N, Co, D, H, W, bias in ((1, 32, 5, 6, 128, False), (2, 40, 4, 9, 100, True), (1, 32, 4, 8, 32, False), (2, 32, 5, 9, 33, False), (1, 40, 8, 16, 64, True), (3, 8, 6, 7, 10, False)):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, 1, D, H, W, generator=g)
     w = torch.randn(Co, 1, 3, 3, 3, generator=g)

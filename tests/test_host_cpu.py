@@ -63,7 +63,8 @@ def test_kernel_choice_queries():
     name = HF.conv_fwd_kernel_name(S, 32, 64)
     assert name in ("conv3d_k3_fwd_wz_kernel<32, 4, 1, false>", "conv3d_k3_fwd_wzy_kernel"), name
     # first layer
-    assert HF.conv_fwd_kernel_name(S, 32, 1, fused=True) in ("conv3d_k3_fwd_kernel<32, 4, 2, 1, true>", "conv3d_k3_fwd_c1_kernel")
+    assert HF.conv_fwd_kernel_name(S, 32, 1, fused=True) == "conv3d_k3_fwd_c1w_kernel"
+    assert HF.conv_fwd_kernel_name((80, 80, 80), 32, 1, fused=True) == "conv3d_k3_fwd_c1_kernel"
     assert HF.conv_fwd_kernel_name((16, 16, 16), 512, 256, fused=True) == "conv3d_k3_fwd_wz_kernel<16, 8, 2, true>"
     wz = HF.conv_wgrad_kernel_name(64, S, 64, 128, 64, lazy=True)
     assert wz in ("conv3d_k3_wgrad_wz_kernel<16, 2, 4, 2, true>", "conv3d_k3_wgrad_wzy_kernel<true>"), wz
