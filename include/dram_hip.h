@@ -301,7 +301,9 @@ int dram_pcm_attention_split_bwd(const float* theta, const float* phi, const flo
 /* The merge types without a softmax (models.py:300-302 cosine, 307-320 heu1 / heu2): a per-edge similarity v_e of
  * (theta_i, phi_j), normalised by its sum over the node's edges: attn_e = v_e / (eps + sum_k v_k).
  * mode 0 cosine: v = F.cosine_similarity (eps 1e-8; sum eps 0); 1 heu1: u = theta.phi / (1 + |theta - phi|_1), v = u if
- * u >= 0.03 else 0 (the mask carries no gradient); 2 heu2: v = relu(u); sum eps 1e-7.  F <= 64.  ds: scratch [B,E,D,H,W]. */
+ * u >= 0.03 else 0; 2 heu2: v = relu(u); sum eps 1e-7.  F <= 64.  ds: scratch [B,E,D,H,W].  (The reference forms heu1's masked
+ * similarities under torch.no_grad(), models.py:311-314: its attention is a constant of the graph, and the host side does not
+ * call the backward entry for mode 1; the entry itself differentiates through the unmasked pairs.) */
 int dram_pcm_attention_sum_fwd(const float* theta, const float* phi, const int* offsets, int E, int mode, float* attn,
                                int B, int F, int D, int H, int W, void* stream);
 int dram_pcm_attention_sum_bwd(const float* theta, const float* phi, const float* attn, const float* dattn,
