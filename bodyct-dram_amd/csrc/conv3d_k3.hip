@@ -719,6 +719,13 @@ __global__ __launch_bounds__(256, 3) void conv3d_k3_fwd_c1w_kernel(ConvArgs a) {
                                __builtin_bit_cast(unsigned, v3)};
             const unsigned vo = full_tile ? voff : (((cmask >> r) & 1u) ? voff : OOB);
             __builtin_amdgcn_raw_buffer_store_b128(pk, dsrd, (int)vo, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * S4), 0);
+            // A > 64-bit buffer store still reads its data registers in the cycles after issue.  hipcc 7.2 only separates a
+            // following write of those registers when soffset is an immediate; with an SGPR soffset it emitted
+            // "buffer_store_dwordx4 v[104:107] ... s58 ; v_mov_b32 v104, ..." back to back and, measured on gfx950, ~0.7 % of
+            // the first dwords at 128^3 then carried the NEXT channel's value (timing dependent).  Two wait states, pinned.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (a.stats) {
             const int pidx = ((((bz * a.nby) + by) * a.nbx + bx) * 4 + wave) * BY + row;

@@ -8,7 +8,7 @@ from dram_amd import _lib
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 p = lambda t: None if t is None else t.data_ptr()
-for N, Co, D, H, W, bias in ((1, 32, 5, 6, 128, False), (2, 40, 4, 9, 100, True), (1, 32, 4, 8, 32, False), (2, 32, 5, 9, 33, False), (1, 40, 8, 16, 64, True), (3, 8, 6, 7, 10, False)):
+for N, Co, D, H, W, bias in ((1, 32, 5, 6, 128, False), (2, 40, 4, 9, 100, True), (1, 32, 4, 8, 32, False), (2, 32, 5, 9, 33, False), (1, 40, 8, 16, 64, True), (3, 8, 6, 7, 10, False), (1, 32, 16, 64, 128, False), (1, 32, 128, 128, 128, False), (2, 32, 64, 128, 128, False)):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, 1, D, H, W, generator=g)
     w = torch.randn(Co, 1, 3, 3, 3, generator=g)
@@ -35,4 +35,12 @@ for N, Co, D, H, W, bias in ((1, 32, 5, 6, 128, False), (2, 40, 4, 9, 100, True)
         pr = parts.view(N, Co, nparts, 3).cpu().double()
         cnt = pr[..., 2].sum(-1)
         mean = (pr[..., 0] * pr[..., 2]).sum(-1) / cnt
-        print("  counts ok", bool((cnt == D * H * W).all()), "mean err", (mean - ref.mean(dim=(2, 3, 4))).abs().max().item())
+        m2 = (pr[..., 1] + pr[..., 2] * (pr[..., 0] - mean[..., None]) ** 2).sum(-1)
+        print("  counts ok", bool((cnt == D * H * W).all()), "mean err", (mean - ref.mean(dim=(2, 3, 4))).abs().max().item(),
+              "var rel err", ((m2 / cnt - ref.var(dim=(2, 3, 4), unbiased=False)).abs() / ref.var(dim=(2, 3, 4), unbiased=False)).max().item())
+        y1, p1 = y.clone(), parts.clone()
+        parts.zero_()
+        _lib.call("dram_conv3d_k3_fwd_fused", p(xd), 1, None, 0, None, 0, None, 0, 0, 0, 0, 0, 0, 0, p(wt), None,
+                  p(y), p(parts), nparts, N, Co, D, H, W, st)
+        torch.cuda.synchronize()
+        print("  rerun bitwise equal: y", bool((y1 == y).all()), "parts", bool((p1 == parts).all()))
