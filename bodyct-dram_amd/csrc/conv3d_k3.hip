@@ -33,6 +33,7 @@
 // The input of forward and the output of backward-data may be a *virtual*
 // channel concatenation of two tensors (crop_concat_5d fused away).
 #include "common.h"
+#include "lane_reduce.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <atomic>
@@ -41,6 +42,7 @@ namespace dram {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // channels [0,C1) live in p1 (spatial D,H,W); channels [C1,C1+C2) in p2 (spatial
 // D2,H2,W2) seen through a crop window starting at (oz,oy,ox).
@@ -122,62 +124,6 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Exchange with the lane `M` away inside each half of the wave (M = 1, 2, 4, 8, 16): ds_swizzle in bit-mask mode
-// (and 0x1f, or 0, xor M) -- no address register, unlike the ds_bpermute behind __shfl_xor.
-template <int M>
-__device__ __forceinline__ float swz_xor(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1f | (M << 10)));
-}
-
-// Sum a per-lane array over the 32 lanes that share lane>>5 ("half" of the wave = the 32 positions of a 32x32 MFMA
-// tile), for NREG = 16 or 32 registers at once: each step exchanges half of the live registers with the lane
-// H away and keeps the other half, so NREG registers cost NREG - 1 (+16 for NREG = 16) exchanges instead of
-// 5 * NREG.  On return x[0] of lane j holds the sum over its half of register (j % NREG).
-template <int H, int NREG>
-__device__ __forceinline__ void transpose_reduce_step(float (&x)[NREG], int lane) {
-    const bool up = (lane & H) != 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const float keep = up ? x[i + H] : x[i];
-        const float send = up ? x[i] : x[i + H];
-        x[i] = keep + swz_xor<H>(send);
-    }
-}
-template <int NREG>
-__device__ __forceinline__ void lane_transpose_reduce(float (&x)[NREG], int lane) {
-    static_assert(NREG == 16 || NREG == 32, "16 or 32 registers");
-    if (NREG == 16) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] += swz_xor<16>(x[i]);
-    } else {
-        transpose_reduce_step<(NREG == 32 ? 16 : 8)>(x, lane);
-    }
-    transpose_reduce_step<8>(x, lane);
-    transpose_reduce_step<4>(x, lane);
-    transpose_reduce_step<2>(x, lane);
-    transpose_reduce_step<1>(x, lane);
-}
-// The inverse: lane j holds in x[0] the value that belongs to register (j % NREG); on return every lane of the
-// half holds all NREG values, x[i] = the value of register i.
-template <int H, int NREG>
-__device__ __forceinline__ void transpose_broadcast_step(float (&x)[NREG], int lane) {
-    const bool up = (lane & H) != 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const float mine = x[i], theirs = swz_xor<H>(mine);
-        x[i] = up ? theirs : mine;
-        x[i + H] = up ? mine : theirs;
-    }
-}
-template <int NREG>
-__device__ __forceinline__ void lane_transpose_broadcast(float (&x)[NREG], int lane) {
-    transpose_broadcast_step<1>(x, lane);
-    transpose_broadcast_step<2>(x, lane);
-    transpose_broadcast_step<4>(x, lane);
-    transpose_broadcast_step<8>(x, lane);
-    if (NREG == 32) transpose_broadcast_step<(NREG == 32 ? 16 : 8)>(x, lane);
-}
-
 // Statistics of a conv output tile in the epilogue (BatchNorm / GroupNorm moments without a pass over the tensor).
 // A lane holds, for each of its NREG = 16*COT accumulator registers i (channel ch(i) below) two outputs Y(0,i),
 // Y(1,i) (valid if ok0 / ok1).  Per wave half and channel: two-pass {mean, M2} over the <= 64 valid values
@@ -190,24 +136,48 @@ __device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lan
     const int j = lane & 31, kh = lane >> 5;
     const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
     const float nvalid = (float)(__popcll(__ballot(ok0) & half) + __popcll(__ballot(ok1) & half));
+    // interior boxes (every lane's two outputs inside the volume: wave-uniform): no selects, packed fp32 arithmetic
+    const bool all_valid = __ballot(ok0 && ok1) == ~0ull;
     float s[NREG];
+    if (all_valid) {
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) s[i] = (ok0 ? Y(0, i) : 0.f) + (ok1 ? Y(1, i) : 0.f);
+        for (int i = 0; i < NREG; i += 2) {
+            const f32x2 y0 = {Y(0, i), Y(0, i + 1)}, y1 = {Y(1, i), Y(1, i + 1)};
+            const f32x2 t = y0 + y1;
+            s[i] = t[0];
+            s[i + 1] = t[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) s[i] = (ok0 ? Y(0, i) : 0.f) + (ok1 ? Y(1, i) : 0.f);
+    }
     lane_transpose_reduce<NREG>(s, lane);
     const float mean_j = nvalid > 0.f ? s[0] / nvalid : 0.f;
     __builtin_amdgcn_sched_barrier(0);     // keep the two phases apart: the sums are dead before the deviations are born
     float q[NREG];
     q[0] = mean_j;
     lane_transpose_broadcast<NREG>(q, lane);                      // q[i] = mean of register i's channel
+    if (all_valid) {
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) {
-        const float d0 = Y(0, i) - q[i], d1 = Y(1, i) - q[i];
-        q[i] = (ok0 ? d0 * d0 : 0.f) + (ok1 ? d1 * d1 : 0.f);
+        for (int i = 0; i < NREG; i += 2) {
+            const f32x2 m = {q[i], q[i + 1]};
+            const f32x2 y0 = {Y(0, i), Y(0, i + 1)}, y1 = {Y(1, i), Y(1, i + 1)};
+            const f32x2 d0 = y0 - m, d1 = y1 - m;
+            const f32x2 t = d0 * d0 + d1 * d1;
+            q[i] = t[0];
+            q[i + 1] = t[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const float d0 = Y(0, i) - q[i], d1 = Y(1, i) - q[i];
+            q[i] = (ok0 ? d0 * d0 : 0.f) + (ok1 ? d1 * d1 : 0.f);
+        }
     }
     lane_transpose_reduce<NREG>(q, lane);
-    const int i = j % NREG;
+    const int i = lane_register_index<NREG>(lane);
     const int co = co0 + 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * kh;   // channel of register i (MFMA 32x32 layout)
-    if (j < NREG && co < Cout) {
+    if (lane_writes_total<NREG>(lane) && co < Cout) {
         float* o = stats + ((row0 + co) * (int64_t)nparts + pidx) * 3;
         o[0] = mean_j;
         o[1] = q[0];
@@ -251,9 +221,9 @@ __device__ __forceinline__ void stats_epilogue_tiles(YF Y, OKF OK, int lane, flo
         q[i] = acc;
     }
     lane_transpose_reduce<16>(q, lane);
-    const int i = j % 16;
+    const int i = lane_register_index<16>(lane);
     const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-    if (j < 16 && co < Cout) {
+    if (lane_writes_total<16>(lane) && co < Cout) {
         float* o = stats + ((row0 + co) * (int64_t)nparts + pidx) * 3;
         o[0] = mean_j;
         o[1] = q[0];
@@ -1045,10 +1015,13 @@ struct FwdWzyGeom {
     static constexpr int W_STAGE = 48 * WT_STRIDE;      // 12288 floats
     static constexpr int STAGE = IN_STAGE + W_STAGE;    // one stage: inputs, then filters
     static constexpr int WPASS = W_STAGE / 4 / 512;     // 16-byte slots per thread and chunk
-    static constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(float);
+    // raw input rows as they come from memory (LDS-DMA, 16 bytes per lane): [ci 4][z plane 4][row 6][40 floats = x0 - 4 .. x0 + 35],
+    // double-buffered (the chunk after next lands while the next one is transformed)
+    static constexpr int RAW_ROW = 40, RAW_PLANE = 6 * RAW_ROW, RAW_CI = 4 * RAW_PLANE, RAW_STAGE = 4 * RAW_CI;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + 2 * RAW_STAGE) * sizeof(float);
+    static_assert(LDS_BYTES <= 160 * 1024, "one block per CU: the whole LDS");
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // v_mov_b32 with a DPP lane pattern (quad_perm 0x00-0xFF, row_ror:n 0x120 + n, row_mirror 0x140), every lane enabled
@@ -1118,11 +1091,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     const float e_say = e_r == 3 ? -1.f : 1.f, e_sby = (e_r & 1) ? 1.f : -1.f;
     const bool e_mid = e_r == 1 || e_r == 2;
     // per staged item (set_staging_item):
-    unsigned off1[4], off2[4];     // in-plane byte offsets of the patch rows in source 1 / 2 (OOB: outside, or no item)
     unsigned rowmask[4];           // all ones / zero: row inside the volume
-    const float* sg_base1 = nullptr;   // sample n of source 1 / 2
-    const float* sg_base2 = nullptr;
     int sg_z0 = 0, sg_row1 = 0, sg_row2 = 0;
+    // ---- fetch role (every wave): the raw rows of channel c0 + (wave >> 1), half (wave & 1) of its 240 16-byte pieces
+    // [plane 4][row 6][x piece 10], by two LDS-DMA instructions (64 + 56 lanes).  Per fetched item (set_fetch_item):
+    const int d_ci = wave >> 1, d_half = wave & 1;
+    unsigned dv1[2], dv2[2];       // byte offset of the lane's piece inside a channel of source 1 / 2 (OOB: outside the volume)
+    const float* dg_base1 = nullptr;   // sample n of source 1 / 2
+    const float* dg_base2 = nullptr;
     unsigned wvoff = 0;            // filter slot 0 of the item's channel tile; slot p is 8 filter matrices further
     const int nchunk = (Cin + 3) >> 2;
     const unsigned wchunk_bytes = 16u * (unsigned)a.Cout;
@@ -1153,30 +1129,41 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             decode(k, item, n, x0, y0, z0, co0);
             sg_z0 = z0;
             const int kC1 = k->src.C1, kC2 = k->src.C2;
-            sg_base1 = k->src.p1 + (size_t)n * kC1 * S;
-            sg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : sg_base1;
             sg_row1 = n * kC1;
             sg_row2 = n * kC2 - kC1;
             const int gx = x0 - 1 + i_hx;
-            const int oy = k->src.oy, ox = k->src.ox, W2 = k->src.W2;
-            if (EXTRA) {             // one element per lane: its whole offset (plane included) and validity
+            if (EXTRA) {             // one element per lane: its validity (plane included)
                 const int gy = y0 - 1 + 2 * i_ty + e_r, gz = z0 - 1 + e_q;
                 const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
-                off1[0] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
-                off2[0] = ok ? 4u * (unsigned)(((gz + k->src.oz) * k->src.H2 + gy + oy) * W2 + gx + ox) : OOB;
                 rowmask[0] = ok ? 0xffffffffu : 0u;
             } else {
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int gy = y0 - 1 + 2 * i_ty + r;
                     const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
-                    off1[r] = ok ? 4u * (unsigned)(gy * W + gx) : OOB;
-                    off2[r] = ok ? 4u * (unsigned)((gy + oy) * W2 + gx + ox) : OOB;
                     rowmask[r] = ok ? 0xffffffffu : 0u;
                 }
             }
             const int t = tid >> 6, r = tid & 63;
             wvoff = 4u * (unsigned)(((t * nchunk) * 2 + (r >> 5)) * k->Cout * 2 + co0 * 2 + 4 * (r & 31));
+        };
+        auto set_fetch_item = [&](int item) {
+            KArgs k = kargs();
+            int n, x0, y0, z0, co0;
+            decode(k, item, n, x0, y0, z0, co0);
+            const int kC1 = k->src.C1, kC2 = k->src.C2;
+            dg_base1 = k->src.p1 + (size_t)n * kC1 * S;
+            dg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : dg_base1;
+            const int oz = k->src.oz, oy = k->src.oy, ox = k->src.ox, H2 = k->src.H2, W2 = k->src.W2;
+    #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = d_half * 120 + 64 * i + lane;         // (lanes >= 56 of the second instruction: masked off at issue)
+                const int pl = c / 60, row = (c % 60) / 10, xc = c % 10;
+                const int gz = z0 - 1 + pl, gy = y0 - 1 + row, gx = x0 - 4 + 4 * xc;    // W % 4 == 0: a piece is inside or outside as a whole
+                const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
+                dv1[i] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
+                dv2[i] = ok ? 4u * (unsigned)(((gz + oz) * H2 + gy + oy) * W2 + gx + ox) : OOB;
+            }
         };
 
         // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
@@ -1212,52 +1199,54 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         unsigned relu_bits = (a.relu1 ? 1u : 0u) | (a.relu2 ? 2u : 0u);
         asm volatile("" : "+v"(cfp[0]), "+v"(cfp[1]), "+v"(cfp[2]), "+v"(cfp[3]), "+v"(relu_bits));
 
-        // The next chunk's loads, in pieces that are issued between MFMAs: piece 0/1 = z planes 0,1 / 2,3 of the patch (+ the
-        // channel's {a, b}), piece 2/3 = the two halves of the filter tile (last: loads return in order, and the patch is
-        // wanted first, mid-chunk; the filters at the barrier).
-        auto load_piece = [&](int c0, float* nstage, int piece) {
-            if (piece < 2) {
-                const int ci = c0 + s_ci;                        // wave-uniform
-                const bool first = ci < C1;
-                const unsigned sx = (unsigned)(first ? S : S2);
-                const float* base = (first ? sg_base1 : sg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
-                const unsigned bytes = ci < Cin ? 4u * sx : 0u;
-                const float* up = uniform_ptr(base);
-                const unsigned plane = first ? plane1 : plane2;
-                const int zadd = first ? 0 : src_oz;
-                if (EXTRA) {
-                    if (piece == 0) rin[0][0] = buf_load(make_rsrc(up, bytes), first ? off1[0] : off2[0], 0u);
-                } else {
-    #pragma unroll
-                    for (int q = 2 * piece; q < 2 * piece + 2; ++q) {
-                        const int gz = sg_z0 - 1 + q;
-                        const bool zok = gz >= 0 && gz < D;
-                        const __amdgpu_buffer_rsrc_t srd = make_rsrc(up, zok ? bytes : 0u);   // a plane outside the volume: all zeros
-                        const unsigned so = zok ? (unsigned)(gz + zadd) * plane : 0u;
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) rin[q][r] = buf_load(srd, first ? off1[r] : off2[r], so);
-                    }
-                }
-                if (piece == 1 && lazy) {   // the channel's {a, b}: one (wave-uniform address) vector load -- keeps the scalar
-                                            // memory path, which shares its counter with the LDS operand reads, out of the loop
-                    const unsigned plo = __builtin_amdgcn_readfirstlane(first ? cfp[0] : cfp[2]);
-                    const unsigned phi = __builtin_amdgcn_readfirstlane(first ? cfp[1] : cfp[3]);
-                    const float* cf = (const float*)(((unsigned long long)phi << 32) | plo);
-                    const unsigned rb = __builtin_amdgcn_readfirstlane(relu_bits);
-                    lc_has = cf != nullptr && ci < Cin;
-                    const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
-                    const __amdgpu_buffer_rsrc_t csrd = make_rsrc(cf, lc_has ? 0x7ffffff0u : 0u);
-                    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
-                    lc_ab = __builtin_bit_cast(f32x2, raw);
-                    lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
-                }
+        // The raw rows of chunk c0 of the fetched item -> raw buffer `rawbuf`: out-of-volume pieces arrive as zeros (range
+        // check of the lane offset), a channel past Cin as zeros (empty descriptor).
+        auto fetch_issue = [&](int c0, float* rawbuf) {
+            const int ci = c0 + d_ci;                            // wave-uniform
+            const bool first = ci < C1;
+            const unsigned sx = (unsigned)(first ? S : S2);
+            const float* base = (first ? dg_base1 : dg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
+            const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(base), ci < Cin ? 4u * sx : 0u);
+            float* dst = rawbuf + d_ci * G::RAW_CI + d_half * 480;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, (int)(first ? dv1[0] : dv2[0]), 0, 0, 0);
+            if (lane < 56)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(dst + 256), 16, (int)(first ? dv1[1] : dv2[1]), 0, 0, 0);
+        };
+        // the patch of the lane (waves 0-3) / its one element (waves 4-7) out of the raw buffer
+        auto read_raw = [&](const float* rawbuf) {
+            if (EXTRA) {
+                rin[0][0] = rawbuf[s_ci * G::RAW_CI + (e_q * 6 + 2 * i_ty + e_r) * G::RAW_ROW + 3 + i_hx];
             } else {
-                const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+                const float* pr = rawbuf + s_ci * G::RAW_CI + (2 * i_ty) * G::RAW_ROW + 3 + i_hx;
     #pragma unroll
-                for (int p = (piece - 2) * (WPASS / 2); p < (piece - 1) * (WPASS / 2); ++p)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
-                                                             (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
+                for (int q = 0; q < 4; ++q)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) rin[q][r] = pr[(q * 6 + r) * G::RAW_ROW];
             }
+        };
+        // the staged chunk's {a, b} of channel c0 + s_ci (normalise on load): one (wave-uniform address) vector load -- keeps
+        // the scalar memory path, which shares its counter with the LDS operand reads, out of the loop
+        auto load_coef = [&](int c0) {
+            const int ci = c0 + s_ci;                            // wave-uniform
+            const bool first = ci < C1;
+            const unsigned plo = __builtin_amdgcn_readfirstlane(first ? cfp[0] : cfp[2]);
+            const unsigned phi = __builtin_amdgcn_readfirstlane(first ? cfp[1] : cfp[3]);
+            const float* cf = (const float*)(((unsigned long long)phi << 32) | plo);
+            const unsigned rb = __builtin_amdgcn_readfirstlane(relu_bits);
+            lc_has = cf != nullptr && ci < Cin;
+            const unsigned row = (unsigned)((first ? sg_row1 : sg_row2) + ci);
+            const __amdgpu_buffer_rsrc_t csrd = make_rsrc(cf, lc_has ? 0x7ffffff0u : 0u);
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(csrd, 0, (int)(8u * row), 0);
+            lc_ab = __builtin_bit_cast(f32x2, raw);
+            lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
+        };
+        // the staged chunk's filter tile, in two halves: global -> LDS directly
+        auto load_filters = [&](int c0, float* nstage, int half) {
+            const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
+    #pragma unroll
+            for (int p = half * (WPASS / 2); p < (half + 1) * (WPASS / 2); ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+                                                         (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
         };
         // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
         // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
@@ -1424,8 +1413,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
 #endif
         };
 
-        // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged,
-        // exactly one chunk ahead.
+        // ---- the pipeline.  Cursors: (c_item, c_c0) = the chunk being multiplied, (s_item, s_c0) = the chunk being staged
+        // (raw rows -> transformed tile, filters), exactly one chunk ahead, (d_item, d_c0) = the chunk whose raw rows are being
+        // fetched, two chunks ahead.  Raw buffer of a chunk = parity of its number in the stream = stage parity.
+        float* const raw0 = lds + 2 * STAGE;
         int s_item = item_lo, s_c0 = 0;
         auto advance_staging = [&]() {
             s_c0 += 4;
@@ -1435,9 +1426,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 if (s_item < item_hi) set_staging_item(s_item);
             }
         };
+        int d_item = item_lo, d_c0 = 0;
+        auto advance_fetch = [&]() {
+            d_c0 += 4;
+            if (d_c0 >= Cin) {
+                d_c0 = 0;
+                d_item += item_step;
+                if (d_item < item_hi) set_fetch_item(d_item);
+            }
+        };
+        // prologue: raw rows of the first two chunks, filters of the first; the first chunk transformed into stage 0
         set_staging_item(s_item);
-    #pragma unroll
-        for (int piece = 0; piece < 4; ++piece) load_piece(0, lds, piece);     // prologue: the first chunk straight into stage 0
+        set_fetch_item(d_item);
+        fetch_issue(0, raw0);
+        advance_fetch();
+        if (d_item < item_hi) { fetch_issue(d_c0, raw0 + G::RAW_STAGE); advance_fetch(); }
+        if (lazy) load_coef(0);
+        load_filters(0, lds, 0);
+        load_filters(0, lds, 1);
+        __syncthreads();                            // (waits for the wave's own loads first: the raw rows of all waves are in)
+        read_raw(raw0);
         if (lazy) { activate(0); activate(1); }
         transform_z();
     #pragma unroll
@@ -1454,18 +1462,27 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // The work that rides between the MFMAs of iteration `it`, in two pieces (after the 2nd / the 3rd MFMA), so that no
         // gap between two MFMAs of a wave is much longer than it has to be: the two waves of a SIMD run in step, and whatever
         // both do between two MFMAs is matrix-pipe idle time.  Staging slices run unconditionally: without a next chunk
-        // they move stale registers into the idle stage.
-        auto ride = [&](int it, int half, bool has_next, float* nstage) {
-            if (it == LD_IN && has_next) load_piece(s_c0, nstage, half);
-            if (it == LD_W && has_next) load_piece(s_c0, nstage, 2 + half);
+        // they move stale data into the idle stage.
+        auto ride = [&](int it, int half, bool has_next, bool has_fetch, float* nstage, int cur_) {
+    #ifndef DRAM_WZY_DIAG_NOPATCH       // (diagnostic builds, scripts/diag_wzy_stamps.py: what a part of the staging costs)
+            if (it == LD_IN && half == 0 && has_fetch) fetch_issue(d_c0, raw0 + cur_ * G::RAW_STAGE);
+    #endif
+            if (it == LD_IN && half == 1 && has_next && lazy) load_coef(s_c0);
+    #ifndef DRAM_WZY_DIAG_NOFILT
+            if (it == LD_W && has_next) load_filters(s_c0, nstage, half);
+    #endif
+    #ifndef DRAM_WZY_DIAG_NOSTAGE
+            if (it == SL0 - 1 && half == 1) read_raw(raw0 + (cur_ ^ 1) * G::RAW_STAGE);
             if (it == SL0 && lazy) activate(half);
             if (it == SL0 + 1 && half == 0) transform_z();
             const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
             if (q >= 0 && q < 4) transform_y_store(nstage + st_idx, q);
+    #endif
         };
         for (;;) {
             const bool c_valid = c_item < item_hi;
             const bool has_next = s_item < item_hi;
+            const bool has_fetch = d_item < item_hi;
             const bool boundary = pending && (c_c0 == 0);     // the previous chunk completed an item
             const float* stage = lds + cur * STAGE;
             float* nstage = lds + (cur ^ 1) * STAGE;
@@ -1490,7 +1507,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                         const int h = m & 1, k = m >> 1, xi = (2 * i0 + h) & 7;
                         acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i0 & 1][h][k], bv[i0 & 1][h][k], acc[xi], 0, 0, 0);
                     }
-                    if (m == 1 || m == 2) ride(it, m - 1, has_next, nstage);
+                    if (m == 1 || m == 2) ride(it, m - 1, has_next, has_fetch, nstage, cur);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (it == 0) {
@@ -1519,6 +1536,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             // latency they cover (measured, MFMAs before / behind the barrier: 0/4 is 1-2 % faster than 2/2, 4/0 1 % slower).
             pending = true;
             if (has_next) advance_staging();
+            if (has_fetch) advance_fetch();
     #ifdef DRAM_WZY_STAMPS
             { const unsigned long long tb = __builtin_readcyclecounter(); st_acc[4] += tb - tp; tp = tb; }
     #endif
@@ -2612,6 +2630,10 @@ static bool use_wzy(const ConvArgs& a) {
     const int64_t dmax = (int64_t)a.D * a.H * a.W > (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2 ? (int64_t)a.D * a.H * a.W
                                                                                               : (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2;
     if (dmax * 4 * 36 > 0xffffffffLL) return false;                             // ... behind one 32-bit descriptor
+    // input rows are fetched as aligned 16-byte pieces (LDS-DMA) behind one descriptor per channel
+    if (a.W % 4 != 0 || (int64_t)a.D * a.H * a.W * 4 >= (int64_t)OOB) return false;
+    if ((((unsigned long long)a.src.p1) | ((unsigned long long)a.src.p2)) & 15ull) return false;
+    if (a.src.p2 && (a.src.W2 % 4 != 0 || a.src.ox % 4 != 0 || (int64_t)a.src.D2 * a.src.H2 * a.src.W2 * 4 >= (int64_t)OOB)) return false;
     const double padded = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2;
     return padded <= 1.2 * (double)a.W * a.H * a.D;
 }

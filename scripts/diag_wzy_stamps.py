@@ -5,7 +5,7 @@ Build first:  cd bodyct-dram_amd/csrc && for f in *.hip; do hipcc -O3 -std=c++17
 import ctypes, os
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-lib = ctypes.CDLL(os.path.join(ROOT, "scripts", "libdram_hip_stamp.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "scripts", os.environ.get("DRAM_STAMP_LIB", "libdram_hip_stamp.so")))
 P, I = ctypes.c_void_p, ctypes.c_int
 lib.dram_conv3d_k3_fwd_fused.argtypes = [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, P, I, I, I, I, I, I, P]
 lib.dram_conv3d_k3_pack_weights.argtypes = [P, P, I, I, I, P]

@@ -130,7 +130,8 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     assert HF.conv_fwd_kernel_name((11, 8, 32), 64, 128, fused=True) == "conv3d_k3_fwd_wzy_kernel"
     assert HF.conv_fwd_kernel_name((12, 11, 32), 64, 64) == "conv3d_k3_fwd_wzy_kernel"
     assert "wz_kernel" in HF.conv_fwd_kernel_name((5, 7, 32), 128, 64)          # too much padding (1.37)
-    assert HF.conv_fwd_kernel_name((2, 4, 58), 192, 64) == "conv3d_k3_fwd_wzy_kernel"
+    assert HF.conv_fwd_kernel_name((2, 4, 56), 192, 64) == "conv3d_k3_fwd_wzy_kernel"
+    assert "wz_kernel" in HF.conv_fwd_kernel_name((2, 4, 58), 192, 64)         # rows are fetched as aligned 16-byte pieces: W % 4
     assert "wz_kernel" in HF.conv_fwd_kernel_name((3, 9, 70), 64, 64)          # too much padding
     assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 32), 16, 64)          # 16 output channels
     assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel"
@@ -152,7 +153,7 @@ def test_conv3d_k3_wzy_concat_and_split():
     32-channel boundary (backward-data of the same conv)."""
     from dram_amd import functional as HF
     up = torch.randn(1, 32, 4, 8, 32, generator=g(15))
-    skip = torch.randn(1, 32, 6, 11, 35, generator=g(16))
+    skip = torch.randn(1, 32, 6, 11, 40, generator=g(16))      # (crop window at x offset 4: rows stay 16-byte aligned)
     Ci, Co = 64, 64
     w = torch.randn(Co, Ci, 3, 3, 3, generator=g(17)) / (Ci * 27) ** 0.5
     gy = torch.randn(1, Co, 4, 8, 32, generator=g(18))
@@ -160,8 +161,11 @@ def test_conv3d_k3_wzy_concat_and_split():
     yr = O.conv3d(O.crop_concat_5d(ur, sr), wr, None, 1)
     yr.backward(gy)
     ug, sg, wg = dev(up).requires_grad_(True), dev(skip).requires_grad_(True), dev(w).requires_grad_(True)
+    before = HF.conv_launch_counts()
     y = HF.conv3d_k3(ug, wg, None, skip=sg)
     y.backward(dev(gy))
+    torch.cuda.synchronize()
+    assert HF.conv_launch_counts()[HF.K3_FWD_WZY] - before[HF.K3_FWD_WZY] == 2      # forward and backward-data
     check(y, yr, "wzy cat conv fwd")
     check(ug.grad, ur.grad, "wzy cat conv d(up)")
     check(sg.grad, sr.grad, "wzy cat conv d(skip)")
@@ -171,7 +175,7 @@ def test_conv3d_k3_wzy_concat_and_split():
 @pytest.mark.parametrize("case", [
     # N, C1, C2, Cout, D, H, W, lazy, stats
     (1, 12, 0, 64, 11, 8, 32, True, True),       # odd D, channel tail
-    (1, 16, 0, 64, 12, 11, 58, True, True),      # ragged y pair and ragged x box
+    (1, 16, 0, 64, 12, 11, 60, True, True),      # ragged y pair and ragged x box
     (2, 10, 0, 128, 4, 12, 64, True, False),
     (1, 8, 8, 64, 8, 8, 32, True, True),         # virtual concat, both sources lazy
     (1, 64, 0, 192, 8, 16, 32, False, True),     # statistics of a plain source, three channel tiles
@@ -188,8 +192,8 @@ def test_conv3d_k3_wzy_fused(case):
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: None if t is None else t.data_ptr()
     x = dev(torch.randn(N, C1, D, H, W, generator=g(21)))
-    x2 = dev(torch.randn(N, C2, D + 2, H + 3, W + 1, generator=g(22))) if C2 else None
-    crop = (1, 2, 1) if C2 else (0, 0, 0)
+    x2 = dev(torch.randn(N, C2, D + 2, H + 3, W + 4, generator=g(22))) if C2 else None
+    crop = (1, 2, 4) if C2 else (0, 0, 0)
     w = dev(torch.randn(Co, Ci, 3, 3, 3, generator=g(23)) / (Ci * 27) ** 0.5)
     coef = dev(torch.rand(N * C1 * 2, generator=g(24)) + 0.5) if lazy else None
     coef2 = dev(torch.rand(N * C2 * 2, generator=g(25)) - 0.2) if (lazy and C2) else None
@@ -205,9 +209,11 @@ def test_conv3d_k3_wzy_fused(case):
             nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W) if stats else 0
             parts = torch.full((N * Co * nparts * 3,), float("nan"), device=d) if stats else None
             d2 = (0, 0, 0) if x2 is None else tuple(x2.shape[2:])
+            before = HF.conv_launch_counts()
             _lib.call("dram_conv3d_k3_fwd_fused", p(x), C1, p(coef), 1, p(x2), C2, p(coef2), 1, d2[0], d2[1], d2[2], crop[0], crop[1],
                       crop[2], p(wt), None, p(y), p(parts), nparts, N, Co, D, H, W, st)
             torch.cuda.synchronize()
+            assert HF.conv_launch_counts()[HF.K3_FWD_WZY] - before[HF.K3_FWD_WZY] == (1 if wzy else 0), case
         finally:
             os.environ.pop("DRAM_CONV_NO_WZY", None)
         return y, parts, nparts
