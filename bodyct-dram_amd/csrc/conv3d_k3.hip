@@ -1095,8 +1095,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     int sg_z0 = 0, sg_row1 = 0, sg_row2 = 0;
     // ---- fetch role (every wave): the raw rows of channel c0 + (wave >> 1), half (wave & 1) of its 240 16-byte pieces
     // [plane 4][row 6][x piece 10], by two LDS-DMA instructions (64 + 56 lanes).  Per fetched item (set_fetch_item):
-    const int d_ci = wave >> 1, d_half = wave & 1;
-    unsigned dv1[2], dv2[2];       // byte offset of the lane's piece inside a channel of source 1 / 2 (OOB: outside the volume)
+    const int d_ci = wave & 3;
+    unsigned dv1[4], dv2[4];       // byte offset of the lane's piece inside a channel of source 1 / 2 (OOB: outside the volume)
     const float* dg_base1 = nullptr;   // sample n of source 1 / 2
     const float* dg_base2 = nullptr;
     unsigned wvoff = 0;            // filter slot 0 of the item's channel tile; slot p is 8 filter matrices further
@@ -1156,8 +1156,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             dg_base2 = k->src.p2 ? k->src.p2 + (size_t)n * kC2 * S2 : dg_base1;
             const int oz = k->src.oz, oy = k->src.oy, ox = k->src.ox, H2 = k->src.H2, W2 = k->src.W2;
     #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = d_half * 120 + 64 * i + lane;         // (lanes >= 56 of the second instruction: masked off at issue)
+            for (int i = 0; i < 4; ++i) {
+                const int c = 64 * i + lane;                        // (lanes >= 48 of the last instruction: masked off at issue)
                 const int pl = c / 60, row = (c % 60) / 10, xc = c % 10;
                 const int gz = z0 - 1 + pl, gy = y0 - 1 + row, gx = x0 - 4 + 4 * xc;    // W % 4 == 0: a piece is inside or outside as a whole
                 const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
@@ -1201,16 +1201,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
 
         // The raw rows of chunk c0 of the fetched item -> raw buffer `rawbuf`: out-of-volume pieces arrive as zeros (range
         // check of the lane offset), a channel past Cin as zeros (empty descriptor).
-        auto fetch_issue = [&](int c0, float* rawbuf) {
+        auto fetch_issue = [&](int c0, float* rawbuf, int i) {
+            if (!EXTRA) return;
             const int ci = c0 + d_ci;                            // wave-uniform
             const bool first = ci < C1;
             const unsigned sx = (unsigned)(first ? S : S2);
             const float* base = (first ? dg_base1 : dg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
             const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(base), ci < Cin ? 4u * sx : 0u);
-            float* dst = rawbuf + d_ci * G::RAW_CI + d_half * 480;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, (int)(first ? dv1[0] : dv2[0]), 0, 0, 0);
-            if (lane < 56)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(dst + 256), 16, (int)(first ? dv1[1] : dv2[1]), 0, 0, 0);
+            float* dst = rawbuf + d_ci * G::RAW_CI + 256 * i;
+            if (i < 3 || lane < 48)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, (int)(first ? dv1[i] : dv2[i]), 0, 0, 0);
         };
         // the patch of the lane (waves 0-3) / its one element (waves 4-7) out of the raw buffer
         auto read_raw = [&](const float* rawbuf) {
@@ -1438,9 +1438,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // prologue: raw rows of the first two chunks, filters of the first; the first chunk transformed into stage 0
         set_staging_item(s_item);
         set_fetch_item(d_item);
-        fetch_issue(0, raw0);
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) fetch_issue(0, raw0, i);
         advance_fetch();
-        if (d_item < item_hi) { fetch_issue(d_c0, raw0 + G::RAW_STAGE); advance_fetch(); }
+        if (d_item < item_hi) {
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) fetch_issue(d_c0, raw0 + G::RAW_STAGE, i);
+            advance_fetch();
+        }
         if (lazy) load_coef(0);
         load_filters(0, lds, 0);
         load_filters(0, lds, 1);
@@ -1465,7 +1470,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // they move stale data into the idle stage.
         auto ride = [&](int it, int half, bool has_next, bool has_fetch, float* nstage, int cur_) {
     #ifndef DRAM_WZY_DIAG_NOPATCH       // (diagnostic builds, scripts/diag_wzy_stamps.py: what a part of the staging costs)
-            if (it == LD_IN && half == 0 && has_fetch) fetch_issue(d_c0, raw0 + cur_ * G::RAW_STAGE);
+            if (it < 2 && has_fetch) fetch_issue(d_c0, raw0 + cur_ * G::RAW_STAGE, 2 * it + half);
     #endif
             if (it == LD_IN && half == 1 && has_next && lazy) load_coef(s_c0);
     #ifndef DRAM_WZY_DIAG_NOFILT
