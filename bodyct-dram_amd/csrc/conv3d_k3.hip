@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     // SL0), the filter tile three iterations later (wanted at the chunk's end; never in iteration 0, where an item's epilogue
     // uses the idle stage as its exchange buffer).  Measured (plain / fused launches, against patch 1 + filters 2): patch 0 +
     // filters 2: -5 % / -1 %; patch 0 + filters 3 or 4: -6.4 % / -2...0 %; patch 0 + filters 1: +0 % / +2 %.
-    constexpr int LD_IN = 0, LD_W = 3;
+    constexpr int LD_IN = 0, LD_W = 2;
     static_assert(8 * 32 * 64 <= STAGE, "the epilogue exchange fits one (idle) stage");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1241,12 +1241,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
         };
         // the staged chunk's filter tile, in two halves: global -> LDS directly
-        auto load_filters = [&](int c0, float* nstage, int half) {
+        auto load_filters = [&](int c0, float* nstage, int p) {       // piece p of WPASS
             const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
-    #pragma unroll
-            for (int p = half * (WPASS / 2); p < (half + 1) * (WPASS / 2); ++p)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
-                                                         (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+                                                     (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
         };
         // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
         // tail: identity resp. zeros in, zeros out).  Branch-free per element: row validity as bit masks on b and lo.
@@ -1447,8 +1445,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             advance_fetch();
         }
         if (lazy) load_coef(0);
-        load_filters(0, lds, 0);
-        load_filters(0, lds, 1);
+    #pragma unroll
+        for (int p = 0; p < WPASS; ++p) load_filters(0, lds, p);
         __syncthreads();                            // (waits for the wave's own loads first: the raw rows of all waves are in)
         read_raw(raw0);
         if (lazy) { activate(0); activate(1); }
@@ -1474,7 +1472,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     #endif
             if (it == LD_IN && half == 1 && has_next && lazy) load_coef(s_c0);
     #ifndef DRAM_WZY_DIAG_NOFILT
-            if (it == LD_W && has_next) load_filters(s_c0, nstage, half);
+            if (it >= LD_W && it < LD_W + WPASS / 2 && has_next) load_filters(s_c0, nstage, 2 * (it - LD_W) + half);
     #endif
     #ifndef DRAM_WZY_DIAG_NOSTAGE
             if (it == SL0 - 1 && half == 1) read_raw(raw0 + (cur_ ^ 1) * G::RAW_STAGE);
