@@ -148,6 +148,28 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     assert delta[HF.K3_WGRAD_WZ] + delta[HF.K3_WGRAD_WZY] == 1 and sum(delta) == 3, delta
 
 
+def test_conv3d_k3_wzy_needs_aligned_rows():
+    """The (z,y) forward kernel fetches input rows as aligned 16-byte pieces (LDS-DMA): a source that starts 4 bytes off a
+    16-byte boundary must be served by the z-only kernel -- and give the same values."""
+    from dram_amd import functional as HF
+    x = torch.randn(1, 64, 4, 8, 32, generator=g(41))
+    w = torch.randn(64, 64, 3, 3, 3, generator=g(42)) * 0.05
+    ref = O.conv3d(x, w, None, 1)
+    store = torch.empty(x.numel() + 4, device=DEV)
+    outs = []
+    for shift, wzy_launches in ((0, 1), (1, 0)):
+        xv = store[shift:shift + x.numel()].view_as(x)
+        xv.copy_(x)
+        assert xv.data_ptr() % 16 == 4 * shift
+        before = HF.conv_launch_counts()
+        y = HF.conv3d_k3(xv, dev(w))
+        torch.cuda.synchronize()
+        after = HF.conv_launch_counts()
+        assert after[HF.K3_FWD_WZY] - before[HF.K3_FWD_WZY] == wzy_launches, (shift, before, after)
+        check(y, ref, f"conv fwd, source {4 * shift} bytes off alignment")
+        outs.append(y)
+
+
 def test_conv3d_k3_wzy_concat_and_split():
     """Winograd-(z,y) kernel with a virtual concat source (forward) and a destination split over two tensors at a
     32-channel boundary (backward-data of the same conv)."""
