@@ -137,7 +137,8 @@ __device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lan
     const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
     const float nvalid = (float)(__popcll(__ballot(ok0) & half) + __popcll(__ballot(ok1) & half));
     // interior boxes (every lane's two outputs inside the volume: wave-uniform): no selects, packed fp32 arithmetic
-    const bool all_valid = __ballot(ok0 && ok1) == ~0ull;
+    const bool all_valid = NREG == 16 && __ballot(ok0 && ok1) == ~0ull;     // (32 registers: the second code path costs the z-only
+                                                                            //  kernels 27 spilled registers and ~1 %)
     float s[NREG];
     if (all_valid) {
 #pragma unroll
