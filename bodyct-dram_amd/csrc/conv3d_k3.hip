@@ -1032,7 +1032,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 
 #ifdef DRAM_WZY_STAMPS      // diagnostics build only (scripts/diag_wzy_stamps.py): s_memtime shares of the chunk loop
-__device__ unsigned long long g_wzy_stamps[16];
+__device__ unsigned long long g_wzy_stamps[32];      // [0 .. 15]: waves 0-3, [16 .. 31]: waves 4-7
 #endif
 
 // One instantiation serves plain and fused launches (lazy operands / statistics are runtime-uniform options): a separate
@@ -1520,9 +1520,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                     if (boundary) epilogue(c_item - item_step, nstage);     // (the stage to fill is idle: its loads come after)
     #ifdef DRAM_WZY_STAMPS
                     if (!c_valid && lane == 0)
-                        for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[i], st_acc[i]);
+                        for (int i = 0; i < 10; ++i) atomicAdd(&g_wzy_stamps[(EXTRA ? 16 : 0) + i], st_acc[i]);
                     if (!c_valid && lane == 0)
-                        for (int i = 0; i < 6; ++i) atomicAdd(&g_wzy_stamps[10 + i], ep_acc[i]);
+                        for (int i = 0; i < 6; ++i) atomicAdd(&g_wzy_stamps[(EXTRA ? 16 : 0) + 10 + i], ep_acc[i]);
     #endif
                     if (!c_valid) return;
                     __builtin_amdgcn_sched_barrier(0);
@@ -2980,7 +2980,7 @@ using namespace dram;
 
 #ifdef DRAM_WZY_STAMPS
 extern "C" int dram_debug_wzy_stamps(unsigned long long* out, int reset) {
-    unsigned long long z[16] = {};
+    unsigned long long z[32] = {};
     if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wzy_stamps), z, sizeof(z));
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wzy_stamps), sizeof(z));
 }

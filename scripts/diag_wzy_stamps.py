@@ -27,15 +27,17 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
                                          wt.data_ptr(), None, y.data_ptr(), None if pt is None else pt.data_ptr(),
                                          nparts if pt is not None else 0, N, Co, S, S, S, st)
             torch.cuda.synchronize()
-        out = (ctypes.c_ulonglong * 16)()
-        lib.dram_debug_wzy_stamps(out, 0)
-        n0, nb = out[7], out[8]
-        nch = n0 + nb
-        names = ["it0", "it1-2", "it3-6", "it7-11", "pre-barrier", "barrier", "it0 at boundary (epilogue)"]
-        per = [out[0] / max(n0, 1), out[1] / nch, out[2] / nch, out[3] / nch, out[4] / nch, out[5] / nch, out[6] / max(nb, 1)]
-        tot = sum(out[q] for q in range(7)) / nch
-        print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s}: cycles per wave and chunk {tot:.0f}: " +
-              ", ".join(f"{names[q]} {per[q]:.0f}" for q in range(7)), flush=True)
-        ne = max(out[15], 1)
-        en = ["A^T along y", "exchange write + barrier", "read + combine + barrier", "statistics", "stores"]
-        print(f"        epilogue per wave and item: " + ", ".join(f"{en[q]} {out[10 + q] / ne:.0f}" for q in range(5)), flush=True)
+        out32 = (ctypes.c_ulonglong * 32)()
+        lib.dram_debug_wzy_stamps(out32, 0)
+        for role, base in (("waves 0-3", 0), ("waves 4-7", 16)):
+            out = [out32[base + q] for q in range(16)]
+            n0, nb = out[7], out[8]
+            nch = n0 + nb
+            names = ["it0", "it1-2", "it3-6", "it7-11", "pre-barrier", "barrier", "it0 at boundary (epilogue)"]
+            per = [out[0] / max(n0, 1), out[1] / nch, out[2] / nch, out[3] / nch, out[4] / nch, out[5] / nch, out[6] / max(nb, 1)]
+            tot = sum(out[q] for q in range(7)) / nch
+            print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s} {role}: cycles per wave and chunk {tot:.0f}: " +
+                  ", ".join(f"{names[q]} {per[q]:.0f}" for q in range(7)), flush=True)
+            ne = max(out[15], 1)
+            en = ["A^T along y", "exchange write + barrier", "read + combine + barrier", "statistics", "stores"]
+            print(f"        epilogue per wave and item: " + ", ".join(f"{en[q]} {out[10 + q] / ne:.0f}" for q in range(5)), flush=True)
