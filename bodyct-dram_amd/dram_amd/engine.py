@@ -18,8 +18,9 @@ Saved for backward per stage: the raw output and {a, b, mean, rstd} -- about 0.4
 (DESIGN.md section 5), with values bit-identical to that path's (same fmaf / fmaxf on the same inputs).
 
 Not an oracle and not a fallback: every step is a kernel of libdram_hip.so.  Networks the engine does not cover
-(SyncBatchNorm, PReLU, dropout, `lite` blocks, conv kernels other than 3x3x3, checkpoint_mode="recompute") run the
-per-op path.
+(PReLU, dropout, `lite` blocks, conv kernels other than 3x3x3, checkpoint_mode="recompute") run the per-op path.
+"sbn" (cross-rank BatchNorm, parts.py:32-33) is covered: the per-rank statistics of the conv epilogue are combined over the
+process group (_sync_forward_stats), and so are the two sums of the norm's backward.
 """
 import os as _os
 
@@ -105,7 +106,7 @@ def _stage_modules(seq):
     if not isinstance(conv, HipConv3d) or conv.kernel_size != (3, 3, 3) or conv.padding != (1, 1, 1) \
             or conv.stride != (1, 1, 1) or conv.dilation != (1, 1, 1) or conv.groups != 1 or conv.bias is not None:
         return None
-    if isinstance(norm, HipSyncBatchNorm) or not isinstance(norm, (HipBatchNorm3d, HipGroupNorm)):
+    if not isinstance(norm, (HipBatchNorm3d, HipGroupNorm)):        # (HipSyncBatchNorm is a HipBatchNorm3d: _sync_group)
         return None
     if not isinstance(act, HipReLU):
         return None
@@ -140,7 +141,7 @@ def parameters_of(model):
 class _Stage:
     """What backward needs of one conv -> norm -> ReLU stage."""
     __slots__ = ("conv", "norm", "inp", "skip", "geom", "y", "coef", "mean", "rstd", "kind", "groups", "batch_stats",
-                 "out", "need_input_grad", "ranges")
+                 "out", "need_input_grad", "ranges", "sync")
 
 
 def _norm_plan(norm, training):
@@ -150,6 +151,49 @@ def _norm_plan(norm, training):
         return NORM_GROUP, norm.num_groups, True, None, None, 0.0
     use_batch, eaf, rm, rv = norm.bookkeeping()
     return NORM_BATCH, 1, use_batch, rm, rv, eaf
+
+
+def _sync_group(norm, use_batch):
+    """(True, group) if this norm is "sbn" (parts.py:32-33) in a run whose batch statistics must span the ranks of its
+    process group: training-mode HipSyncBatchNorm with torch.distributed initialised on more than one rank -- the
+    condition of HipSyncBatchNorm.forward.  Otherwise (False, None): plain BatchNorm, as nn.SyncBatchNorm is in the
+    reference's single-process runs."""
+    if not use_batch or not isinstance(norm, HipSyncBatchNorm):
+        return False, None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(norm.process_group) > 1):
+        return False, None
+    return True, norm.process_group
+
+
+def _sync_forward_stats(norm, group, mean, rstd, coef, count, rm, rv, eaf, N, Co, st):
+    """Cross-rank combine of a stage's batch statistics (what functional.SyncBatchNormFn.forward does for the per-op
+    path): all-gather of {mean, M2, count} per channel, Chan's formula in fp64, running statistics from the GLOBAL
+    moments, then mean / rstd / per-row {a, b} rewritten from them.  `mean`, `rstd` hold this rank's statistics on entry
+    (dram_norm_finalize_parts without running buffers).  Returns the global element count per channel."""
+    import torch.distributed as dist
+    eps = float(norm.eps)
+    dev = mean.device
+    var_l = rstd.double().pow(-2) - eps                      # this rank's biased variance
+    local = torch.cat([mean.double(), var_l * float(count), torch.tensor([float(count)], dtype=torch.float64, device=dev)])
+    world = dist.get_world_size(group)
+    allst = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(allst, local, group=group)
+    allst = torch.stack(allst)                               # [world, 2 Co + 1]
+    cnt = allst[:, 2 * Co].view(world, 1)
+    means, m2s = allst[:, :Co], allst[:, Co:2 * Co]
+    total = cnt.sum()
+    gmean = (means * cnt).sum(0) / total
+    m2 = (m2s + cnt * (means - gmean) ** 2).sum(0)
+    gvar = m2 / total
+    gmean_f, gvar_f = gmean.float(), gvar.float()
+    if rm is not None:
+        with torch.no_grad():
+            unb = (m2 / (total - 1.0)).float() if float(total) > 1.0 else gvar_f
+            rm.mul_(1.0 - eaf).add_(gmean_f, alpha=eaf)
+            rv.mul_(1.0 - eaf).add_(unb, alpha=eaf)
+    call("dram_bn_eval_coef", _p(norm.weight), _p(norm.bias), _p(gmean_f), _p(gvar_f), _p(mean), _p(rstd), _p(coef), eps, N, Co, st)
+    return float(total)
 
 
 # A stage whose first input is an Upsampled recipe runs in slices of samples when the upsampled tensor (and, in
@@ -225,10 +269,15 @@ def _conv_stage(conv, norm, inp, skip, training, record, plan):
                        int(sk.relu) if sk is not None else 0, D2, H2, W2, oz, oy, ox, _p(wt), None, _p(y[lo:hi]),
                        _p(parts[lo * Co * nparts * 3:]) if use_batch else None, nparts, n, Co, D, H, W, st)
         del x1
+    sync, group = _sync_group(norm, training and use_batch and kind == NORM_BATCH)
+    total = None
     if use_batch:
         ws = _ws(_lib.lib.dram_norm_parts_ws_bytes(N, Co, nparts), dev)
-        call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef), _p(rm), _p(rv),
+        call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef),
+             None if sync else _p(rm), None if sync else _p(rv),
              float(eaf), float(norm.eps), kind, groups, N, Co, S, _p(ws), ws.numel(), st)
+        if sync:        # "sbn": the statistics span the ranks (two small exchanges per stage and direction)
+            total = _sync_forward_stats(norm, group, mean, rstd, coef, N * S, rm, rv, float(eaf), N, Co, st)
     else:   # eval-mode BatchNorm: coefficients from the running statistics
         call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
     out = Lazy(y, coef, relu=True)
@@ -240,6 +289,7 @@ def _conv_stage(conv, norm, inp, skip, training, record, plan):
         s.geom = (C1, C2, D2, H2, W2, oz, oy, ox)
         s.y, s.coef, s.mean, s.rstd = y, coef, mean, rstd
         s.kind, s.groups, s.batch_stats, s.out = kind, groups, bool(use_batch), out
+        s.sync = (group, total) if sync else None
         s.ranges = ranges
         record.append(("conv", s))
     return out
@@ -462,8 +512,22 @@ def backward(model, record, gout, need_dx):
             g_in = g
             if _os.environ.get("DRAM_ENGINE_NO_INPLACE"):
                 g = torch.empty_like(g_in)
-            call("dram_norm_bwd", _p(g_in), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(g), _p(dgamma), _p(dbeta),
-                 s.kind, s.groups, 1, int(s.batch_stats), N, Co, S, _p(ws), ws.numel(), st)
+            if s.sync is not None:      # "sbn": the two backward sums span the ranks; the parameter gradients stay local sums
+                import torch.distributed as dist
+                group, total = s.sync
+                sums = torch.empty(2 * Co, dtype=torch.float64, device=g.device)
+                call("dram_bn_bwd_sums", _p(g_in), _p(s.y), _p(s.mean), _p(s.rstd), _p(s.coef), _p(sums), 1, N, Co, S,
+                     _p(ws), ws.numel(), st)
+                if dbeta is not None:
+                    dbeta.copy_(sums[0::2])
+                if dgamma is not None:
+                    dgamma.copy_(sums[1::2])
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+                call("dram_bn_bwd_apply_sums", _p(g_in), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(sums),
+                     float(total), _p(g), 1, N, Co, S, _p(ws), ws.numel(), st)
+            else:
+                call("dram_norm_bwd", _p(g_in), _p(s.y), _p(gamma), _p(s.mean), _p(s.rstd), _p(s.coef), _p(g), _p(dgamma), _p(dbeta),
+                     s.kind, s.groups, 1, int(s.batch_stats), N, Co, S, _p(ws), ws.numel(), st)
             del g_in
             if dgamma is not None:
                 grads[gamma] = dgamma

@@ -71,3 +71,72 @@ def test_sync_batchnorm_without_group_is_batchnorm():
     x = torch.randn(2, 4, 3, 5, 6, device="cuda")
     a, b = HipSyncBatchNorm(4).cuda().train(), HipBatchNorm3d(4).cuda().train()
     assert torch.equal(a(x), b(x))
+
+
+def _engine_worker(rank, world, port, out):
+    """Slim DC3D with "sbn" through the FUSED ENGINE on this rank's share of a batch (statistics combined over the two
+    ranks inside the engine) against one process running the whole batch with "bn" through the same engine."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "bodyct-dram_amd")]
+    import models
+    from dram_amd import engine
+    from dram_amd.configs import SLIM
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def build(norm):
+        torch.manual_seed(11)
+        m = models.DC3D(**SLIM, norm_method=norm)
+        m.init(models.HeNorm(mode="fan_in"))
+        g = torch.Generator().manual_seed(12)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm3d) and mod.weight is not None:
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                    mod.bias.copy_((torch.randint(0, 2, mod.bias.shape, generator=g).float() * 2 - 1) * 3.0)
+        return m.cuda().train()
+
+    g = torch.Generator().manual_seed(13)
+    N, shape = 4, (16, 16, 16)
+    x = torch.randn((N, 1) + shape, generator=g)
+    gout = torch.randn((N, 1) + shape, generator=g)
+    lo, hi = (0, 1) if rank == 0 else (1, 4)            # uneven split: the combine must weight by count
+    m = build("sbn")
+    assert engine.supports(m) and m.fused
+    before = engine.LAST_PLAN
+    d0, _ = m(x[lo:hi].cuda())
+    assert engine.LAST_PLAN is not before               # the engine ran (not the per-op path)
+    (d0 * gout[lo:hi].cuda()).sum().backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for v in grads.values():
+        dist.all_reduce(v)                               # parameter gradients: local sums
+    ok = True
+    if rank == 0:
+        ref = build("bn")
+        r0, _ = ref(x.cuda())
+        (r0 * gout.cuda()).sum().backward()
+        rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+        errs = {"out": rel(d0.detach(), r0.detach()[lo:hi])}
+        for k, p in ref.named_parameters():
+            errs[k] = rel(grads[k], p.grad)
+        for k, v in ref.state_dict().items():
+            if "running" in k:
+                errs[k] = rel(m.state_dict()[k], v)
+        bad = {k: e for k, e in errs.items() if not e <= 2e-4}
+        ok = not bad
+        if bad:
+            print("sbn engine mismatches:", bad, flush=True)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_on_the_fused_engine_two_ranks():
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, 29657, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(0) is True and out.get(1) is True

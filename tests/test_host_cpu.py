@@ -222,7 +222,7 @@ def test_engine_applicability_and_footprint():
     assert engine.supports(models.DC3D(**SLIM))
     for norm in ("bnt", "bntna", "ln", "lnna", "in"):
         assert engine.supports(models.DC3D(**SLIM, norm_method=norm)), norm
-    assert not engine.supports(models.DC3D(**SLIM, norm_method="sbn"))         # cross-rank statistics: per-op path
+    assert engine.supports(models.DC3D(**SLIM, norm_method="sbn"))             # cross-rank statistics: combined inside the engine
     assert not engine.supports(models.DC3D(**SLIM, norm_method=None))          # no norm (and conv biases)
     assert not engine.supports(models.DC3D(**SLIM, act_method="prelu"))
     assert not engine.supports(models.DC3D(**dict(SLIM, dropout=0.1)))
