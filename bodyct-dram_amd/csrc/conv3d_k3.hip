@@ -133,7 +133,7 @@ template <int COT, typename YF>
 __device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lane, float* __restrict__ stats,
                                                int64_t row0, int co0, int Cout, int nparts, int pidx) {
     constexpr int NREG = 16 * COT;
-    const int j = lane & 31, kh = lane >> 5;
+    const int kh = lane >> 5;
     const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
     const float nvalid = (float)(__popcll(__ballot(ok0) & half) + __popcll(__ballot(ok1) & half));
     // interior boxes (every lane's two outputs inside the volume: wave-uniform): no selects, packed fp32 arithmetic
@@ -191,7 +191,7 @@ __device__ __forceinline__ void stats_epilogue(YF Y, bool ok0, bool ok1, int lan
 template <int NT, typename YF, typename OKF>
 __device__ __forceinline__ void stats_epilogue_tiles(YF Y, OKF OK, int lane, float* __restrict__ stats, int64_t row0, int co0, int Cout,
                                                      int nparts, int pidx) {
-    const int j = lane & 31, kh = lane >> 5;
+    const int kh = lane >> 5;
     const unsigned long long half = kh ? 0xffffffff00000000ull : 0x00000000ffffffffull;
     int nv = 0;
 #pragma unroll
@@ -1106,8 +1106,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     const unsigned wpass_bytes = 8u * (unsigned)nchunk * wchunk_bytes;
     const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 48u * 16u * (unsigned)nchunk * (unsigned)a.Cout);
     const int C1 = a.src.C1;
-    const unsigned plane1 = 4u * (unsigned)(H * W), plane2 = 4u * (unsigned)(a.src.H2 * a.src.W2);
-    const int src_oz = a.src.oz;
 
     auto decode = [&](KArgs k, int item, int& n, int& x0, int& y0, int& z0, int& co0) {
         int b = item;
@@ -1124,6 +1122,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     // Both instances execute the same barriers (same trip counts).
     auto run = [&](auto role) {
         constexpr bool EXTRA = decltype(role)::value;
+        if (!EXTRA) __builtin_amdgcn_s_setprio(2);     // the staging waves: their vector instructions meet the partner's MFMA stream (lazy + statistics launches -1...-1.5 %)
         auto set_staging_item = [&](int item) {
             KArgs k = kargs();
             int n, x0, y0, z0, co0;
