@@ -1122,7 +1122,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     // Both instances execute the same barriers (same trip counts).
     auto run = [&](auto role) {
         constexpr bool EXTRA = decltype(role)::value;
-        if (!EXTRA) __builtin_amdgcn_s_setprio(2);     // the staging waves: their vector instructions meet the partner's MFMA stream (lazy + statistics launches -1...-1.5 %)
         auto set_staging_item = [&](int item) {
             KArgs k = kargs();
             int n, x0, y0, z0, co0;
