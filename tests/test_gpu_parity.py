@@ -200,6 +200,7 @@ def test_conv3d_k3_wzy_concat_and_split():
     (1, 16, 0, 64, 12, 11, 60, True, True),      # ragged y pair and ragged x box
     (2, 10, 0, 128, 4, 12, 64, True, False),
     (1, 8, 8, 64, 8, 8, 32, True, True),         # virtual concat, both sources lazy
+    (2, 6, 10, 64, 4, 12, 32, True, True),       # ... with the source boundary inside a 4-channel chunk (raw rows: per-channel source)
     (1, 64, 0, 192, 8, 16, 32, False, True),     # statistics of a plain source, three channel tiles
     (3, 16, 0, 64, 2, 4, 32, True, True),        # one plane pair, one box per sample: items of three samples per block
 ])
