@@ -2625,7 +2625,7 @@ static bool use_wz(const ConvArgs& a) {
 // Which forward kernel / box shape a shape gets (shared by the launch and by dram_conv3d_k3_stats_parts).
 // The Winograd-(z,y) kernel: whole 64-channel output tiles, enough input channels, and a volume that its 32x4x2 boxes
 // cover with little padding (it executes 2/3 of the z-only kernel's MFMAs: worth up to ~1.3x padding, taken at 1.2x).
-static bool use_wzy(const ConvArgs& a) {
+static bool use_wzy_shape(const ConvArgs& a) {       // what the SHAPE allows (dram_conv3d_k3_stats_parts sizes the partials by it)
     const bool off = getenv("DRAM_CONV_NO_WZY") != nullptr;     // (read per call: A/B tests toggle it inside one process)
     if (off || !use_wz(a) || a.Cout % 64 != 0 || a.Cin < 8) return false;
     if (a.dst.C2 > 0 && a.dst.C1 % 32 != 0) return false;                       // a wave's 32 channels: one destination tensor
@@ -2634,11 +2634,18 @@ static bool use_wzy(const ConvArgs& a) {
     if (dmax * 4 * 36 > 0xffffffffLL) return false;                             // ... behind one 32-bit descriptor
     // input rows are fetched as aligned 16-byte pieces (LDS-DMA) behind one descriptor per channel
     if (a.W % 4 != 0 || (int64_t)a.D * a.H * a.W * 4 >= (int64_t)OOB) return false;
-    if ((((unsigned long long)a.src.p1) | ((unsigned long long)a.src.p2)) & 15ull) return false;
-    if (a.src.p2 && (a.src.W2 % 4 != 0 || a.src.ox % 4 != 0 || (int64_t)a.src.D2 * a.src.H2 * a.src.W2 * 4 >= (int64_t)OOB)) return false;
     const double padded = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2;
     return padded <= 1.2 * (double)a.W * a.H * a.D;
 }
+// ... and what the SOURCE of one launch allows on top of that: 16-byte aligned bases, a cropped second source whose rows and
+// window start on 16-byte boundaries.  A launch that fails only this runs the z-only kernel on the SAME 32x4x2 boxes
+// (fwd_choice), so that the number of statistics partials stays a function of the shape alone.
+static bool wzy_source_ok(const ConvArgs& a) {
+    if ((((unsigned long long)a.src.p1) | ((unsigned long long)a.src.p2)) & 15ull) return false;
+    if (a.src.p2 && (a.src.W2 % 4 != 0 || a.src.ox % 4 != 0 || (int64_t)a.src.D2 * a.src.H2 * a.src.W2 * 4 >= (int64_t)OOB)) return false;
+    return true;
+}
+static bool use_wzy(const ConvArgs& a) { return use_wzy_shape(a) && wzy_source_ok(a); }
 
 struct FwdChoice {
     bool c1;            // first-layer kernel (Cin = 1, plain source and destination)
@@ -2687,6 +2694,7 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
         if (const char* f = getenv("DRAM_FWD_BX"))
             for (int i = 0; i < 4; ++i)
                 if (atoi(f) == boxes2[i][0]) best = i;
+        if (use_wzy_shape(a)) best = 0;         // the (z,y) kernel's boxes: refused for its source only (wzy_source_ok)
         c.box = best;
         c.nbx = cdiv(a.W, boxes2[best][0]); c.nby = cdiv(a.H, boxes2[best][1]); c.nbz = cdiv(a.D, 2);
     } else {
@@ -3056,19 +3064,35 @@ extern "C" int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W
     return parts > 0x7fffffffLL ? 0 : (int)parts;
 }
 
-// Which kernel a forward / backward-data call of this shape launches (the same fwd_choice the launch uses).
-extern "C" int dram_conv3d_k3_fwd_choice(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
-                                         int dstW2, int fused, char* name, size_t cap) {
+// Which kernel a forward / backward-data call of this shape launches (the same fwd_choice the launch uses).  The plain query
+// assumes a source the (z,y) kernel accepts (16-byte aligned, no cropped second tensor); dram_conv3d_k3_fwd_choice_src takes
+// the facts of the source that can send a launch to the z-only kernel instead (wzy_source_ok).
+extern "C" int dram_conv3d_k3_fwd_choice_src(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
+                                             int dstW2, int fused, int srcC2, int srcD2, int srcH2, int srcW2, int srcox,
+                                             int src_misaligned, char* name, size_t cap) {
     DRAM_REQUIRE(Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_fwd_choice: non-positive dimension");
     DRAM_REQUIRE(dstC2 == 0 || dstC1 + dstC2 == Cout, "conv3d_k3_fwd_choice: the destination split does not add up to Cout");
+    DRAM_REQUIRE(srcC2 >= 0 && srcC2 < Cin, "conv3d_k3_fwd_choice: the second source holds %d of %d input channels", srcC2, Cin);
     ConvArgs a = {};
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.dst.C1 = dstC2 > 0 ? dstC1 : Cout;
     a.dst.C2 = dstC2 > 0 ? dstC2 : 0;
     a.dst.D2 = dstC2 > 0 ? dstD2 : 1; a.dst.H2 = dstC2 > 0 ? dstH2 : 1; a.dst.W2 = dstC2 > 0 ? dstW2 : 1;
-    static const float dummy = 0.f;
-    if (fused) a.stats = const_cast<float*>(&dummy);          // (only tested for null-ness by fwd_kernel_id)
+    static const float dummy[8] = {};
+    // (pointers are only tested for null-ness / alignment by the choice: a 16-byte aligned dummy, or one 4 bytes off)
+    const float* al = (const float*)(((unsigned long long)dummy + 15ull) & ~15ull);
+    a.src.p1 = const_cast<float*>(src_misaligned ? al + 1 : al);
+    a.src.C1 = Cin - srcC2;
+    if (srcC2 > 0) {
+        a.src.p2 = const_cast<float*>(al);
+        a.src.C2 = srcC2; a.src.D2 = srcD2; a.src.H2 = srcH2; a.src.W2 = srcW2; a.src.ox = srcox;
+    }
+    if (fused) a.stats = const_cast<float*>(dummy);          // (only tested for null-ness by fwd_kernel_id)
     return fwd_kernel_id(a, fwd_choice(a), name, cap);
+}
+extern "C" int dram_conv3d_k3_fwd_choice(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
+                                         int dstW2, int fused, char* name, size_t cap) {
+    return dram_conv3d_k3_fwd_choice_src(Cin, Cout, D, H, W, dstC1, dstC2, dstD2, dstH2, dstW2, fused, 0, 0, 0, 0, 0, 0, name, cap);
 }
 
 // Which kernel a backward-weights call of this shape launches (the same wgrad_plan / wgrad_kernel the launch uses).

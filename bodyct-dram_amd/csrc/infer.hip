@@ -170,6 +170,68 @@ __global__ void threshold_kernel(const float* __restrict__ htp, uint8_t* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) mask[i] = htp[i] > th ? 1 : 0;
 }
 
+// ---- the post-processing tail of LesionSegTest.run (dram/job_runner.py:1003-1012, 1033-1037)
+// w_scan = windowing(scan, from_span=(wmin, wmax), to_span=(0, 1)) (utils.py:189-198: numpy clips the int16 scan, subtracts in
+// integers and divides by float(wmax - wmin): fp64), and binary_cam's 8-bit view of it (utils.py:233: windowing(., (0, 1)) ->
+// (w / 1.0) * 255 + 0 -> astype(uint8) truncates).  The same fp64 operations in the same order, so that bin and comparison
+// are bit-identical to numpy's.
+__device__ __forceinline__ double windowed_scan(int s, int wmin, int wmax) {
+    const int c = s < wmin ? wmin : (s > wmax ? wmax : s);
+    return (double)(c - wmin) / (double)(wmax - wmin);
+}
+
+// hist[b] = #{v : lobe[v] > 0, uint8(w_scan[v] * 255) == b}
+__global__ __launch_bounds__(256) void scan_hist_kernel(const int16_t* __restrict__ scan, const uint8_t* __restrict__ lobe,
+                                                        unsigned long long* __restrict__ hist, int wmin, int wmax, size_t n) {
+    __shared__ unsigned lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        if (lobe[i] > 0) {
+            const double w = windowed_scan((int)scan[i], wmin, wmax);
+            atomicAdd(&lh[(int)((w / 1.0) * 255.0 + 0.0)], 1u);
+        }
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+// lesion_pred = htp > th (job_runner.py:1004);  lesion_pred_post = lesion_pred & (w_scan > th_scan) & ~(vessel > 0) (1008-1010)
+__global__ void lesion_post_kernel(const float* __restrict__ htp, const int16_t* __restrict__ scan,
+                                   const uint8_t* __restrict__ vessel, uint8_t* __restrict__ pred, uint8_t* __restrict__ post,
+                                   float th, int wmin, int wmax, double th_scan, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool p = htp[i] > th;
+        const bool bright = windowed_scan((int)scan[i], wmin, wmax) > th_scan;
+        const bool ves = vessel != nullptr && vessel[i] > 0;
+        if (pred) pred[i] = p ? 1 : 0;
+        post[i] = (p && bright && !ves) ? 1 : 0;
+    }
+}
+
+// counts = {|a & b|, |a | b|, |a|, |b|} of two masks (non-zero = set): what IOU / Dice (utils.py:437-446) are made of
+__global__ __launch_bounds__(256) void mask_overlap_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                           unsigned long long* __restrict__ counts, size_t n) {
+    unsigned c[4] = {0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const bool x = a[i] > 0, y = b[i] > 0;
+        c[0] += x && y; c[1] += x || y; c[2] += x; c[3] += y;
+    }
+    __shared__ unsigned sm[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned v = c[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
 }  // namespace dram
 
 using namespace dram;
@@ -244,4 +306,35 @@ extern "C" int dram_threshold_mask(const float* htp, uint8_t* mask, float th, in
     const unsigned grid = (unsigned)(cdiv64(n, 256) < 4096 ? cdiv64(n, 256) : 4096);
     hipLaunchKernelGGL(threshold_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, htp, mask, th, (size_t)n);
     return check_launch("threshold_mask");
+}
+
+// hist: 256 x uint64 (zeroed here) of binary_cam's 8-bit view of windowing(scan, (wmin, wmax), (0, 1)) inside the lungs
+extern "C" int dram_scan_hist256(const int16_t* scan, const uint8_t* lobe, unsigned long long* hist, int wmin, int wmax,
+                                 int64_t n, void* stream) {
+    DRAM_REQUIRE(scan && lobe && hist && n > 0 && wmax > wmin, "scan_hist256: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), st);
+    const unsigned grid = (unsigned)(cdiv64(n, 256 * 16) < 2048 ? cdiv64(n, 256 * 16) : 2048);
+    hipLaunchKernelGGL(scan_hist_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, scan, lobe, hist, wmin, wmax, (size_t)n);
+    return check_launch("scan_hist256");
+}
+
+// pred (may be NULL) = htp > th;  post = pred & (windowing(scan) > th_scan) & ~(vessel > 0)  (vessel may be NULL: no vessels)
+extern "C" int dram_lesion_post(const float* htp, const int16_t* scan, const uint8_t* vessel, uint8_t* pred, uint8_t* post,
+                                float th, int wmin, int wmax, double th_scan, int64_t n, void* stream) {
+    DRAM_REQUIRE(htp && scan && post && n > 0 && wmax > wmin, "lesion_post: bad arguments");
+    const unsigned grid = (unsigned)(cdiv64(n, 256) < 4096 ? cdiv64(n, 256) : 4096);
+    hipLaunchKernelGGL(lesion_post_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, htp, scan, vessel, pred, post, th,
+                       wmin, wmax, th_scan, (size_t)n);
+    return check_launch("lesion_post");
+}
+
+// counts[4] (uint64, zeroed here) = {intersection, union, |a|, |b|}
+extern "C" int dram_mask_overlap(const uint8_t* a, const uint8_t* b, unsigned long long* counts, int64_t n, void* stream) {
+    DRAM_REQUIRE(a && b && counts && n > 0, "mask_overlap: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), st);
+    const unsigned grid = (unsigned)(cdiv64(n, 256 * 16) < 2048 ? cdiv64(n, 256 * 16) : 2048);
+    hipLaunchKernelGGL(mask_overlap_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, a, b, counts, (size_t)n);
+    return check_launch("mask_overlap");
 }

@@ -61,6 +61,9 @@ SIGNATURES = {
     "dram_lobe_paste": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dram_lung_hist256": (I, [P, P, P, P, L, P]),
     "dram_threshold_mask": (I, [P, P, F, L, P]),
+    "dram_scan_hist256": (I, [P, P, P, I, I, L, P]),
+    "dram_lesion_post": (I, [P, P, P, P, P, F, I, I, ctypes.c_double, L, P]),
+    "dram_mask_overlap": (I, [P, P, P, L, P]),
     "dram_intreg_loss_ws_bytes": (Z, [I, L]),
     "dram_intreg_loss_state_floats": (I, [I]),
     "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),
@@ -88,6 +91,7 @@ SIGNATURES = {
     "dram_conv3d_k3_wgrad_lazy_ok": (I, [I, I, I, I, I, I, I]),
     "dram_conv3d_k3_wgrad_fused": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, P, P, P, Z, I, I, I, I, I, P]),
     "dram_conv3d_k3_fwd_choice": (I, [I, I, I, I, I, I, I, I, I, I, I, c_char_p, Z]),
+    "dram_conv3d_k3_fwd_choice_src": (I, [I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, c_char_p, Z]),
     "dram_conv3d_k3_wgrad_choice": (I, [I, I, I, I, I, I, I, I, c_char_p, Z]),
     "dram_conv3d_k3_launch_counts": (I, [P, I]),
     "dram_norm_parts_ws_bytes": (Z, [I, I, I]),

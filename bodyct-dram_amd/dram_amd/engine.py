@@ -250,7 +250,6 @@ def _conv_stage(conv, norm, inp, skip, training, record, plan):
     rstd = torch.empty(nstat, dtype=torch.float32, device=dev)
     coef = torch.empty(2 * N * Co, dtype=torch.float32, device=dev)
     gamma, beta = norm.weight, norm.bias
-    name = HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True)
     nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W) if use_batch else 0
     parts = torch.empty(N * Co * nparts * 3, dtype=torch.float32, device=dev) if use_batch else None
     ranges = _slices(inp, N, plan.slice_up) if up else [(0, N)]
@@ -263,6 +262,7 @@ def _conv_stage(conv, norm, inp, skip, training, record, plan):
             x1 = inp if (lo, hi) == (0, N) else _lazy_slice(inp, lo, hi)
         sk = None if skip is None else (skip if (lo, hi) == (0, N) else _lazy_slice(skip, lo, hi))
         vox = n * S
+        name = HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True, src=(x1.raw, sk.raw if sk is not None else None, ox))
         HF._timed_call(name, 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                        "dram_conv3d_k3_fwd_fused", _p(x1.raw), C1, _p(x1.coef), int(x1.relu),
                        _p(sk.raw) if sk is not None else None, C2, _p(sk.coef) if sk is not None else None,
@@ -578,7 +578,8 @@ def backward(model, record, gout, need_dx):
                 # backward-data: gradient w.r.t. the activated input(s)
                 if need_dgrad:
                     dx1 = torch.empty((n, C1, D, H, W), dtype=torch.float32, device=g.device)
-                    HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if dx2 is not None else None),
+                    HF._timed_call(HF.conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if dx2 is not None else None,
+                                                           src=(gs, None, 0)),
                                    54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                                    "dram_conv3d_k3_fwd_ex", _p(gs), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                                    _p(dx1), C1, _p(dx2[lo:hi]) if dx2 is not None else None, C2, D2, H2, W2, oz, oy, ox,

@@ -61,16 +61,25 @@ K3_FWD_DIRECT, K3_FWD_WZ, K3_FWD_WZY, K3_WGRAD_DIRECT, K3_WGRAD_VEC, K3_WGRAD_WZ
     K3_FWD_C1, K3_WGRAD_WZY, K3_KINDS = range(11)
 
 
-def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False, dst_split=None):
+def conv_fwd_kernel_name(dhw, Cout, Cin, fused=False, dst_split=None, src=None):
     """Name of the forward / backward-data kernel instantiation the library launches for this shape, as rocprofv3
-    prints it -- asked of the library itself (dram_conv3d_k3_fwd_choice: the same fwd_choice the launch goes through).
+    prints it -- asked of the library itself (dram_conv3d_k3_fwd_choice_src: the same fwd_choice the launch goes through).
     `fused`: the variant with lazy operands / the statistics epilogue; `dst_split` = (C1, C2, D2, H2, W2) when the
-    output is written to two tensors (backward-data of a conv whose input was a virtual concat)."""
+    output is written to two tensors (backward-data of a conv whose input was a virtual concat); `src` = (x1, x2, ox): the
+    source tensors of the launch (x2 the cropped second one or None, ox its window's x offset) -- a source off 16-byte
+    alignment, or a crop window that is, sends a (z,y)-shaped launch to the z-only kernel."""
     c1, c2, d2, h2, w2 = dst_split if dst_split is not None else (Cout, 0, 0, 0, 0)
+    sc2 = sd2 = sh2 = sw2 = sox = mis = 0
+    if src is not None:
+        x1, x2, sox = src
+        mis = int(x1.data_ptr() % 16 != 0 or (x2 is not None and x2.data_ptr() % 16 != 0))
+        if x2 is not None:
+            sc2, sd2, sh2, sw2 = (int(v) for v in x2.shape[1:])
     buf = ctypes.create_string_buffer(96)
-    kind = _lib.lib.dram_conv3d_k3_fwd_choice(Cin, Cout, dhw[0], dhw[1], dhw[2], c1, c2, d2, h2, w2, int(bool(fused)), buf, len(buf))
+    kind = _lib.lib.dram_conv3d_k3_fwd_choice_src(Cin, Cout, dhw[0], dhw[1], dhw[2], c1, c2, d2, h2, w2, int(bool(fused)),
+                                                  sc2, sd2, sh2, sw2, int(sox), mis, buf, len(buf))
     if kind < 0:
-        raise _lib.DramHipError(f"dram_conv3d_k3_fwd_choice: {_lib.lib.dram_last_error().decode()}")
+        raise _lib.DramHipError(f"dram_conv3d_k3_fwd_choice_src: {_lib.lib.dram_last_error().decode()}")
     return buf.value.decode()
 
 
@@ -154,7 +163,7 @@ class Conv3dK3Fn(Function):
         wt = _pack(w, 0)
         y = torch.empty((N, Co, D, H, W), dtype=torch.float32, device=x1.device)
         vox = N * D * H * W
-        _timed_call(conv_fwd_kernel_name((D, H, W), Co, Ci), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+        _timed_call(conv_fwd_kernel_name((D, H, W), Co, Ci, src=(x1, x2, ox)), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                     "dram_conv3d_k3_fwd_ex", _p(x1), C1, _p(x2), C2, D2, H2, W2, oz, oy, ox, _p(wt), _p(bias),
                     _p(y), Co, None, 0, 0, 0, 0, 0, 0, 0, N, D, H, W, _stream())
         ctx.save_for_backward(x1, x2, w)
@@ -181,8 +190,8 @@ class Conv3dK3Fn(Function):
                 full = (D2, H2, W2) == (D, H, W)
                 dx2 = torch.empty_like(x2) if full else torch.zeros_like(x2)
             vox = N * D * H * W
-            _timed_call(conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if x2 is not None else None),
-                        54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
+            _timed_call(conv_fwd_kernel_name((D, H, W), Ci, Co, dst_split=(C1, C2, D2, H2, W2) if x2 is not None else None,
+                                             src=(dy, None, 0)), 54.0 * Ci * Co * vox, 4.0 * (Ci + Co) * vox,
                         "dram_conv3d_k3_fwd_ex", _p(dy), Co, None, 0, 0, 0, 0, 0, 0, 0, _p(wt), None,
                         _p(dx1), C1, _p(dx2), C2, D2, H2, W2, oz, oy, ox, N, D, H, W, st)
             if not need1:

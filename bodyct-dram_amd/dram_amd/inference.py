@@ -62,13 +62,22 @@ class LobeInference:
 
     MAX_CHUNKS = 8     # chunks per kernel call / model batch (csrc/infer.hip MAX_CHUNKS)
 
-    def __init__(self, model, resample_size=80, window=(-1000.0, -300.0), border_mm=5.0, max_labels=255):
+    def __init__(self, model, resample_size=80, window=(-1000.0, -300.0), border_mm=5.0, max_labels=255,
+                 post_window=(-1150, 350), post_scaler=0.75):
         if not 1 <= int(max_labels) <= 255:
             raise ValueError("max_labels must be in 1..255 (uint8 label map)")
         self.model, self.R, self.window, self.border, self.max_labels = model, int(resample_size), window, border_mm, int(max_labels)
+        # the brightness gate of LesionSegTest.run: windowing()'s default span (utils.py:189, job_runner.py:1006) and the 0.75
+        # on its Otsu threshold (job_runner.py:1007)
+        self.post_window, self.post_scaler = (int(post_window[0]), int(post_window[1])), float(post_scaler)
 
     @torch.no_grad()
-    def run(self, scan, lobe, spacing):
+    def run(self, scan, lobe, spacing, vessel=None, lesion=None):
+        """`vessel` (uint8 [D,H,W], optional): the vessel mask of LesionSegTest.run; with it (or with `lesion`) the result also
+        holds the post-processed mask `mask_post` = mask & (windowed scan > brightness threshold) & ~vessel (job_runner.py:1006-1010).
+        `lesion` (uint8 [D,H,W], optional): the reference mask; adds iou / iou_post / dice / dice_post (job_runner.py:1033-1037),
+        computed at the working resolution (the reference first resamples every mask to the original spacing with SimpleITK
+        nearest-neighbour, job_runner.py:1016-1032 -- absent here, the identity when the spacings agree)."""
         dev = next(self.model.parameters()).device
         scan = torch.as_tensor(scan).to(device=dev, dtype=torch.int16).contiguous()
         lobe = torch.as_tensor(lobe).to(device=dev, dtype=torch.uint8).contiguous()
@@ -123,8 +132,51 @@ class LobeInference:
         mask = torch.empty((D, H, W), dtype=torch.uint8, device=dev)
         call("dram_threshold_mask", htp.data_ptr(), mask.data_ptr(), float(th), htp.numel(), st)
         ratio = float(ssum.item()) / max(n_lung, 1)                          # (htp * (lobe>0)).sum() / (lobe>0).sum()
-        return {"htp": htp, "mask": mask, "threshold": th, "lesion_ratio": ratio, "ctss": ratio_to_label(ratio),
-                "chunks": chunks, "input": x}
+        res = {"htp": htp, "mask": mask, "threshold": th, "lesion_ratio": ratio, "ctss": ratio_to_label(ratio),
+               "chunks": chunks, "input": x}
+        if vessel is not None or lesion is not None:
+            res.update(self.post_process(scan, lobe, htp, th, vessel, lesion, mask))
+        return res
+
+    @torch.no_grad()
+    def post_process(self, scan, lobe, htp, th, vessel=None, lesion=None, mask=None):
+        """The tail of LesionSegTest.run (job_runner.py:1006-1012, 1033-1037) on the device: brightness gate
+        `binary_cam(w_scan[lobe > 0], 0.75)` on the scan windowed with windowing()'s default span, lesion_pred_post =
+        lesion_pred & (w_scan > th) & ~(vessel > 0), and IOU / Dice against the reference lesion mask (utils.py:437-446)."""
+        dev = htp.device
+        st = torch.cuda.current_stream().cuda_stream
+        n = htp.numel()
+        vessel = None if vessel is None else torch.as_tensor(vessel).to(device=dev, dtype=torch.uint8).contiguous()
+        if vessel is not None and vessel.shape != htp.shape:
+            raise ValueError("vessel mask and scan must have the same shape")
+        hist = torch.empty(256, dtype=torch.int64, device=dev)
+        call("dram_scan_hist256", scan.data_ptr(), lobe.data_ptr(), hist.data_ptr(), self.post_window[0], self.post_window[1], n, st)
+        th_scan = binary_cam_threshold(hist.cpu().numpy(), self.post_scaler)
+        post = torch.empty(htp.shape, dtype=torch.uint8, device=dev)
+        call("dram_lesion_post", htp.data_ptr(), scan.data_ptr(), None if vessel is None else vessel.data_ptr(), None,
+             post.data_ptr(), float(th), self.post_window[0], self.post_window[1], float(th_scan), n, st)
+        out = {"mask_post": post, "threshold_scan": th_scan}
+        if lesion is not None:
+            lesion = torch.as_tensor(lesion).to(device=dev, dtype=torch.uint8).contiguous()
+            if lesion.shape != htp.shape:
+                raise ValueError("lesion mask and scan must have the same shape")
+            if mask is None:
+                mask = torch.empty(htp.shape, dtype=torch.uint8, device=dev)
+                call("dram_threshold_mask", htp.data_ptr(), mask.data_ptr(), float(th), n, st)
+            counts = torch.empty(8, dtype=torch.int64, device=dev)
+            call("dram_mask_overlap", mask.data_ptr(), lesion.data_ptr(), counts.data_ptr(), n, st)
+            call("dram_mask_overlap", post.data_ptr(), lesion.data_ptr(), counts[4:].data_ptr(), n, st)
+            c = [int(v) for v in counts.cpu()]
+            s = 1e-5                                                        # the smooth term of job_runner.py:1033-1037
+            out.update(iou=(c[0] + s) / (c[1] + s), dice=(2.0 * c[0] + s) / (c[2] + c[3] + s),
+                       iou_post=(c[4] + s) / (c[5] + s), dice_post=(2.0 * c[4] + s) / (c[6] + c[7] + s))
+        return out
+
+
+def iou(predict, target, smooth=1e-5):
+    """dram/utils.py:437-442."""
+    predict, target = np.asarray(predict) > 0, np.asarray(target) > 0
+    return (np.logical_and(predict, target).sum() + smooth) / (np.logical_or(predict, target).sum() + smooth)
 
 
 def dice(predict, target, smooth=1e-5):

@@ -223,6 +223,21 @@ int dram_lung_hist256(const float* htp, const uint8_t* lobe, unsigned long long*
 /* mask[v] = htp[v] > th. */
 int dram_threshold_mask(const float* htp, uint8_t* mask, float th, int64_t n, void* stream);
 
+/* ---- the post-processing tail of LesionSegTest.run (dram/job_runner.py:1003-1012, 1033-1037) ----
+ * w_scan = windowing(scan, from_span=(wmin, wmax), to_span=(0, 1)) (utils.py:189-198; the reference calls it with the default
+ * span (-1150, 350), job_runner.py:1006), in fp64 exactly as numpy evaluates it.
+ * dram_scan_hist256: 256-bin histogram of binary_cam's 8-bit view of w_scan over voxels with lobe > 0 (the input of the
+ *   brightness gate's Otsu threshold, `binary_cam(w_scan[lobe > 0], 0.75)`, job_runner.py:1007).  hist: 256 x uint64.
+ * dram_lesion_post: pred = htp > th (job_runner.py:1004; pred may be NULL), post = pred & (w_scan > th_scan) & ~(vessel > 0)
+ *   (job_runner.py:1008-1010; vessel may be NULL = no vessel mask).
+ * dram_mask_overlap: counts[4] (uint64) = {|a & b|, |a | b|, |a|, |b|} of two uint8 masks (non-zero = set): IOU =
+ *   (counts[0] + s) / (counts[1] + s), Dice = (2 counts[0] + s) / (counts[2] + counts[3] + s) (utils.py:437-446). */
+int dram_scan_hist256(const int16_t* scan, const uint8_t* lobe, unsigned long long* hist, int wmin, int wmax, int64_t n,
+                      void* stream);
+int dram_lesion_post(const float* htp, const int16_t* scan, const uint8_t* vessel, uint8_t* pred, uint8_t* post, float th,
+                     int wmin, int wmax, double th_scan, int64_t n, void* stream);
+int dram_mask_overlap(const uint8_t* a, const uint8_t* b, unsigned long long* counts, int64_t n, void* stream);
+
 /* ---- nn.PReLU (act_wrapper "prelu", dram/parts.py:51-52): y = x > 0 ? x : a*x, a[nparam], nparam in {1, C};
  *      x: [N,C,S].  bwd: dx (may be NULL), da[nparam] = sum dy*x over x <= 0 (deterministic) ---- */
 int dram_prelu_fwd(const float* x, const float* a, float* y, int N, int C, int nparam, int64_t S, void* stream);
@@ -368,6 +383,13 @@ int dram_conv3d_k3_wgrad_fused(const float* x1, int C1, const float* coef1, int 
  * dram_conv3d_k3_fwd_ex (dstC2 = 0: one tensor); fused != 0: the dram_conv3d_k3_fwd_fused variant. */
 int dram_conv3d_k3_fwd_choice(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
                               int dstW2, int fused, char* name, size_t cap);
+/* ... given what the SOURCE of the launch looks like as well: a cropped second source tensor [., srcC2, srcD2, srcH2, srcW2]
+ * whose window starts at x offset srcox, and whether a source base pointer is off 16-byte alignment.  The (z,y) kernel
+ * fetches rows as aligned 16-byte pieces: such a launch runs the z-only kernel on the same 32x4x2 boxes instead (the count of
+ * statistics partials, dram_conv3d_k3_stats_parts, does not depend on it). */
+int dram_conv3d_k3_fwd_choice_src(int Cin, int Cout, int D, int H, int W, int dstC1, int dstC2, int dstD2, int dstH2,
+                                  int dstW2, int fused, int srcC2, int srcD2, int srcH2, int srcW2, int srcox,
+                                  int src_misaligned, char* name, size_t cap);
 /* backward-weights with x = x1[.,C1,..] ++ crop(x2[.,C2,..]) (C2 = 0: one tensor); lazy != 0: the *_fused variant
  * with at least one lazily normalised source. */
 int dram_conv3d_k3_wgrad_choice(int N, int C1, int C2, int Cout, int D, int H, int W, int lazy, char* name, size_t cap);

@@ -495,6 +495,32 @@ def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", r
     return htp, mask, th, ratio
 
 
+def lesion_post_process(htp, scan, lobe, vessel, th, post_window=(-1150, 350), scaler=0.75):
+    """The tail of LesionSegTest.run (dram/job_runner.py:1004-1012) on a finished heat map: lesion_pred = htp > th;
+    w_scan = windowing(scan, to_span=(0, 1)) with windowing()'s DEFAULT from_span (-1150, 350) (utils.py:189);
+    _, th2 = binary_cam(w_scan[lobe > 0], 0.75); lesion_pred_post = lesion_pred & (w_scan > th2) & ~(vessel > 0).
+    Returns (lesion_pred uint8, lesion_pred_post uint8, th2)."""
+    lesion_pred = htp > th
+    w_scan = windowing(scan, from_span=post_window, to_span=(0, 1))
+    _, th2 = binary_cam(w_scan[lobe > 0], scaler)
+    vessel = np.zeros(scan.shape, dtype=np.uint8) if vessel is None else vessel
+    post = np.logical_and(np.logical_and(lesion_pred, w_scan > th2), np.logical_not(vessel > 0)).astype(np.uint8)
+    return lesion_pred.astype(np.uint8), post, th2
+
+
+def iou(predict, target, smooth):
+    """dram/utils.py:437-442."""
+    intersection = np.sum(np.logical_and(predict, target))
+    union = np.sum(np.logical_or(predict, target))
+    return (intersection + smooth) / (union + smooth)
+
+
+def dice(predict, target, smooth):
+    """dram/utils.py:444-446."""
+    intersection = np.sum(np.logical_and(predict, target))
+    return (2.0 * intersection.sum() + smooth) / (predict.sum() + target.sum() + smooth)
+
+
 # --------------------------------------------------------------------------
 # PCM local attention + DC3DATGeneric (SURVEY row N2; reference dram/models.py:150-597)
 #

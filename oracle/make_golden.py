@@ -566,6 +566,33 @@ def gen_affloss():
     _save("affloss", images=_np(images), lobes=_np(lobes), lesions=_np(lesions), ctss=np.array(ctss), theta=_np(theta), **arrs)
 
 
+def gen_infer_tail():
+    """The numpy helpers around the model call of LesionSegTest.run that do NOT need SimpleITK / skimage, run from the
+    reference's utils.py on small random volumes: windowing (utils.py:189-198, with its default span and to_span=(0, 1) as
+    job_runner.py:1006 calls it), binary_cam's 8-bit view of it (utils.py:233: windowing(., from_span=(0, 1)).astype(uint8)),
+    find_crops (utils.py:244-254), IOU and Dice (utils.py:437-446).  (binary_cam itself needs skimage's threshold_otsu: the
+    Otsu step stays unpinned.)"""
+    import utils as U
+    rng = np.random.default_rng(77)
+    shape = (14, 19, 23)
+    scan = rng.integers(-1400, 700, size=shape).astype(np.int16)
+    scan.flat[:8] = [-1150, -1151, 350, 351, -1050, -950, 349, -1149]          # window edges and exact 1/15 steps
+    lobe = np.zeros(shape, dtype=np.uint8)
+    lobe[2:9, 3:12, 4:15] = 1
+    lobe[6:13, 8:17, 10:22] = 3
+    a = (rng.random(shape) > 0.6).astype(np.uint8)
+    b = (rng.random(shape) > 0.5).astype(np.uint8)
+    w_scan = U.windowing(scan, to_span=(0, 1))
+    view8 = U.windowing(w_scan[lobe > 0], from_span=(0, 1)).astype(np.uint8)
+    arrs = dict(scan=scan, lobe=lobe, a=a, b=b, w_scan=w_scan, view8=view8, hist=np.bincount(view8, minlength=256),
+                iou=np.array(U.IOU(a > 0, b > 0, 1e-5)), dice=np.array(U.Dice(a > 0, b > 0, 1e-5)),
+                iou_empty=np.array(U.IOU(np.zeros(shape, bool), np.zeros(shape, bool), 1e-5)))
+    for i, (lab, spacing, border) in enumerate(((1, (1.0, 0.7, 0.7), 5), (3, (2.5, 1.0, 1.0), 5), (3, (1.0, 1.0, 1.0), 0))):
+        sl = U.find_crops(lobe == lab, spacing, border)
+        arrs[f"crop{i}"] = np.array([lab, *spacing, border, *[s.start for s in sl], *[s.stop for s in sl]], dtype=np.float64)
+    _save("infer_tail", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     parts, models = _import_reference()
@@ -590,3 +617,5 @@ if __name__ == "__main__":
         gen_loss2()
     if not only or "affloss" in only:
         gen_affloss()
+    if not only or "infer_tail" in only:
+        gen_infer_tail()

@@ -153,3 +153,109 @@ def test_config5_full_size_whole_scan():
     assert abs(res["threshold"] - th_ref) <= 1.0 / 255.0 + 1e-9
     assert d >= 0.999, d
     assert abs(res["lesion_ratio"] - ratio_ref) <= 1e-5 * max(1.0, abs(ratio_ref))
+
+
+def _full_width_model(kind):
+    """The model process_pipeline.py loads (st_dram_ref_att: DC3DATGeneric, process_pipeline.py:11) / its plain counterpart
+    (st_dram_ref: DC3D) at FULL channel widths, HeNorm-initialised, with non-trivial BatchNorm affine parameters and running
+    statistics -- what eval mode reads."""
+    import models
+    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL, ST_DRAM_REF_MODEL
+    torch.manual_seed(5)
+    m = models.DC3DATGeneric(**ST_DRAM_REF_ATT_MODEL) if kind == "att" else models.DC3D(**ST_DRAM_REF_MODEL)
+    m.init(models.HeNorm(mode="fan_in"))
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm3d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.05)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) * 0.5 + 0.75)
+                mod.weight.copy_(1.0 + 0.2 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+    return m
+
+
+@pytest.mark.parametrize("kind", ["dc3d", "att"])
+def test_full_width_eval_inference_5_lobes_at_80(kind):
+    """Config 5's model path at FULL width (the other inference tests run the slim model): five lobes -> 5 x 80^3 through
+    the fused engine in EVAL mode (BatchNorm from running statistics: dram_bn_eval_coef; levels 80 / 40 / 20 / 10) for
+    DC3D(st_dram_ref) and for DC3DATGeneric(st_dram_ref_att) -- the model process_pipeline.py:11 loads; its refined second
+    output is what evaluate_scan pastes, job_runner.py:764 -- against the oracle's evaluate_scan on the host (one lobe at a
+    time, torch CPU).  Match: job_runner.py:729-770, models.py:543-597.  (The PCM itself stays parity-unpinned: DGL absent.)"""
+    import time
+    from dram_amd import engine
+    from dram_amd import functional as HF
+    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL, ST_DRAM_REF_MODEL
+    from dram_amd.inference import LobeInference, dice, synthetic_ct
+    torch.set_num_threads(16)
+    cfg = ST_DRAM_REF_ATT_MODEL if kind == "att" else ST_DRAM_REF_MODEL
+    scan, lobe, spacing = synthetic_ct((120, 160, 160), (1.0, 0.7, 0.7), seed=7, n_lesions=10)
+    model = _full_width_model(kind)
+    params, buffers = O.split_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    model = model.cuda().eval()
+    assert model.fused and engine.supports(model)
+    before = HF.conv_launch_counts()
+    res = LobeInference(model, resample_size=80).run(scan, lobe, spacing)
+    torch.cuda.synchronize()
+    delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
+    assert [c[6] for c in res["chunks"]] == [1, 2, 3, 4, 5] and tuple(res["input"].shape) == (5, 1, 80, 80, 80)
+    assert sum(delta[k] for k in (HF.K3_FWD_C1, HF.K3_FWD_WZ, HF.K3_FWD_WZY, HF.K3_FWD_DIRECT)) == 14, delta   # one batch of 5
+    fwd = None
+    if kind == "att":
+        fwd = lambda t: O.dc3dat_forward(cfg, params, buffers, t, training=False, attention=True)[1]
+    t0 = time.perf_counter()
+    htp_ref, mask_ref, th_ref, ratio_ref = O.evaluate_scan(cfg, params, buffers, scan, lobe, spacing, resample=80, forward=fwd)
+    cpu_s = time.perf_counter() - t0
+    htp = res["htp"].cpu().numpy()
+    err = float(np.abs(htp - htp_ref).max())
+    d = dice(res["mask"].cpu().numpy(), mask_ref, 1e-5)
+    print(f"\nfull-width {kind} eval, 5 lobes x 80^3: htp max-abs err {err:.2e} (range {htp_ref.min():.3f}..{htp_ref.max():.3f}), "
+          f"mask Dice {d:.6f}, oracle {cpu_s:.1f} s")
+    assert float(htp_ref.max() - htp_ref[lobe > 0].min()) > 1e-3          # not a constant map
+    assert err <= 1e-4 * max(1.0, float(np.abs(htp_ref).max()))
+    assert (htp[lobe == 0] == 0).all()
+    assert abs(res["threshold"] - th_ref) <= 1.0 / 255.0 + 1e-9
+    assert d >= 0.999, d
+    assert abs(res["lesion_ratio"] - ratio_ref) <= 1e-5 * max(1.0, abs(ratio_ref))
+
+
+def test_lesion_post_processing_tail(golden_dir):
+    """The tail of LesionSegTest.run on the device (job_runner.py:1003-1012, 1033-1037; csrc/infer.hip dram_scan_hist256 /
+    dram_lesion_post / dram_mask_overlap): the 8-bit histogram of the default-windowed scan inside the lungs is BIT-exact
+    against the reference's own numbers (tests/golden/infer_tail.npz), lesion_pred_post = lesion_pred & (w_scan > th) & ~vessel
+    and IOU / Dice equal the oracle's restatement bit for bit (integer / fp64 work) on a synthetic scan through LobeInference."""
+    import os
+    from dram_amd import _lib
+    from dram_amd.inference import LobeInference, synthetic_ct
+    z = np.load(os.path.join(golden_dir, "infer_tail.npz"))
+    st = torch.cuda.current_stream().cuda_stream
+    scan_d, lobe_d = torch.as_tensor(z["scan"]).cuda(), torch.as_tensor(z["lobe"]).cuda()
+    hist = torch.empty(256, dtype=torch.int64, device="cuda")
+    _lib.call("dram_scan_hist256", scan_d.data_ptr(), lobe_d.data_ptr(), hist.data_ptr(), -1150, 350, scan_d.numel(), st)
+    assert np.array_equal(hist.cpu().numpy(), z["hist"])
+    a_d, b_d = torch.as_tensor(z["a"]).cuda(), torch.as_tensor(z["b"]).cuda()
+    counts = torch.empty(4, dtype=torch.int64, device="cuda")
+    _lib.call("dram_mask_overlap", a_d.data_ptr(), b_d.data_ptr(), counts.data_ptr(), a_d.numel(), st)
+    c = [int(v) for v in counts.cpu()]
+    assert (c[0] + 1e-5) / (c[1] + 1e-5) == float(z["iou"]) and (2.0 * c[0] + 1e-5) / (c[2] + c[3] + 1e-5) == float(z["dice"])
+
+    scan, lobe, spacing = synthetic_ct((60, 96, 96), (1.0, 0.7, 0.7), seed=7, n_lesions=8)
+    rng = np.random.default_rng(3)
+    vessel = ((rng.random(scan.shape) > 0.9) & (lobe > 0)).astype(np.uint8)
+    lesion = ((scan > -600) & (lobe > 0)).astype(np.uint8)
+    model = _model().cuda().eval()
+    res = LobeInference(model, resample_size=32).run(scan, lobe, spacing, vessel=vessel, lesion=lesion)
+    htp = res["htp"].cpu().numpy()
+    pred_ref, post_ref, th2_ref = O.lesion_post_process(htp, scan, lobe, vessel, res["threshold"])
+    assert res["threshold_scan"] == th2_ref
+    mask, post = res["mask"].cpu().numpy(), res["mask_post"].cpu().numpy()
+    assert np.array_equal(mask, pred_ref) and np.array_equal(post, post_ref)
+    assert (post <= mask).all() and (post[vessel > 0] == 0).all()
+    print(f"\npost-processing tail: |mask| {int(mask.sum())}, |mask_post| {int(post.sum())}, brightness threshold {th2_ref:.4f}, "
+          f"iou {res['iou']:.4f} -> {res['iou_post']:.4f}")
+    assert res["iou"] == O.iou(pred_ref > 0, lesion > 0, 1e-5) and res["iou_post"] == O.iou(post_ref > 0, lesion > 0, 1e-5)
+    assert res["dice"] == O.dice(pred_ref > 0, lesion > 0, 1e-5) and res["dice_post"] == O.dice(post_ref > 0, lesion > 0, 1e-5)
+    # without a vessel mask: only the brightness gate
+    res2 = LobeInference(model, resample_size=32).run(scan, lobe, spacing, lesion=lesion)
+    _, post2, _ = O.lesion_post_process(htp, scan, lobe, None, res["threshold"])
+    assert np.array_equal(res2["mask_post"].cpu().numpy(), post2)

@@ -145,7 +145,7 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     after = HF.conv_launch_counts()
     delta = [a - b for a, b in zip(after, before)]
     assert delta[HF.K3_FWD_WZY] == 2, delta
-    assert delta[HF.K3_WGRAD_WZ] + delta[HF.K3_WGRAD_WZY] == 1 and sum(delta) == 3, delta
+    assert delta[HF.K3_WGRAD_WZY] == 1 and sum(delta) == 3, delta              # (the (z,y) backward-weights kernel, on its own)
 
 
 def test_conv3d_k3_wzy_needs_aligned_rows():
@@ -264,6 +264,132 @@ def test_conv3d_k3_wzy_fused(case):
         assert bool((cnt == D * H * W).all()), case
         assert (mean - r.mean(1)).abs().max().item() < 1e-5, case
         assert ((m2 - ((r - r.mean(1, keepdim=True)) ** 2).sum(1)).abs() / m2).max().item() < 1e-4, case
+
+
+def test_conv3d_k3_fused_forward_source_fallback_keeps_its_partials():
+    """A (z,y)-shaped fused forward whose SOURCE the (z,y) kernel refuses -- a cropped skip whose window starts at x % 4 != 0,
+    a base pointer 4 bytes off a 16-byte boundary -- runs the z-only kernel on the same 32x4x2 boxes, so the statistics buffer
+    sized by dram_conv3d_k3_stats_parts(shape) is exactly what the launch fills (round-3 advisor finding: at H, W = 32, 56 the
+    z-only kernel's own choice is 8x16 boxes with another partial count, and the launch raised)."""
+    from dram_amd import functional as HF
+    from dram_amd import _lib
+    N, C1, C2, Co, D, H, W = 2, 8, 8, 64, 4, 32, 56
+    Ci = C1 + C2
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    w = dev(torch.randn(Co, Ci, 3, 3, 3, generator=g(51)) / (Ci * 27) ** 0.5)
+    wt = HF._pack(w, 0)
+    coef = dev(torch.rand(N * C1 * 2, generator=g(52)) + 0.5)
+    coef2 = dev(torch.rand(N * C2 * 2, generator=g(53)) - 0.2)
+    nparts = _lib.lib.dram_conv3d_k3_stats_parts(Ci, Co, D, H, W)
+    assert nparts == 2 * 8 * 2 * 4
+    x1 = torch.randn(N, C1, D, H, W, generator=g(54))
+    for what, x2shape, shift in (("crop window at x offset 3", (N, C2, D + 2, H + 3, W + 6), 0),
+                                 ("first source 4 bytes off alignment", (N, C2, D, H, W), 1),
+                                 ("aligned sources (control)", (N, C2, D + 2, H + 2, W + 8), 0)):
+        x2 = dev(torch.randn(*x2shape, generator=g(55)))
+        store = torch.empty(x1.numel() + 4, device=DEV)
+        xv = store[shift:shift + x1.numel()].view_as(x1)
+        xv.copy_(x1)
+        assert xv.data_ptr() % 16 == 4 * shift
+        crop = tuple(int(np.ceil((b - a) / 2)) for a, b in zip((D, H, W), x2shape[2:]))
+        control = what.endswith("(control)")
+        assert HF.conv_fwd_kernel_name((D, H, W), Co, Ci, fused=True, src=(xv, x2, crop[2])) == \
+            ("conv3d_k3_fwd_wzy_kernel" if control else "conv3d_k3_fwd_wz_kernel<32, 4, 2, true>"), what
+        y = torch.full((N, Co, D, H, W), float("nan"), device=DEV)
+        parts = torch.full((N * Co * nparts * 3,), float("nan"), device=DEV)
+        before = HF.conv_launch_counts()
+        _lib.call("dram_conv3d_k3_fwd_fused", p(xv), C1, p(coef), 1, p(x2), C2, p(coef2), 1, *x2shape[2:], *crop,
+                  p(wt), None, p(y), p(parts), nparts, N, Co, D, H, W, st)
+        torch.cuda.synchronize()
+        delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
+        assert (delta[HF.K3_FWD_WZY], delta[HF.K3_FWD_WZ]) == ((1, 0) if control else (0, 1)), (what, delta)
+
+        def act(t, cf):
+            c = cf.view(t.shape[0], t.shape[1], 2).double()
+            return torch.relu(t.double() * c[:, :, 0, None, None, None] + c[:, :, 1, None, None, None])
+        win = x2[:, :, crop[0]:crop[0] + D, crop[1]:crop[1] + H, crop[2]:crop[2] + W]
+        ref = torch.nn.functional.conv3d(torch.cat([act(xv, coef), act(win, coef2)], 1).cpu(), w.double().cpu(), None, padding=1)
+        check(y, ref, f"fused forward, {what}")
+        q = parts.view(N * Co, nparts, 3).double()
+        cnt = q[:, :, 2].sum(1)
+        assert bool((cnt == D * H * W).all()), what
+        mean = (q[:, :, 0] * q[:, :, 2]).sum(1) / cnt
+        assert (mean - y.double().view(N * Co, -1).mean(1)).abs().max().item() < 1e-5, what
+
+
+WGRAD_WZY_CASES = [
+    # N, C1, C2, Cout, (D, H, W), skip shape beyond (D, H, W), lazy, bytes off alignment of x1 / dy
+    (3, 16, 16, 64, (4, 6, 16), (2, 3, 4), True, 0),      # review case: two lazy sources, concat boundary at 16, D = 4, W = 16, N = 3
+    (2, 32, 16, 72, (4, 4, 16), (2, 3, 3), True, 0),      # crop window at x offset 2 (ceil(3/2)), rows of 19 floats: unaligned 16-byte pieces
+    (2, 32, 16, 72, (4, 4, 16), (2, 3, 3), False, 0),     # ... plain operands
+    (2, 16, 0, 64, (6, 4, 32), (0, 0, 0), True, 4),       # x and dy 4 bytes off a 16-byte boundary, lazy
+    (1, 48, 0, 130, (4, 8, 16), (0, 0, 0), False, 4),     # ... plain, three co tiles with a tail
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_WZY_CASES)
+def test_conv3d_k3_wgrad_wzy_fused(case):
+    """The Winograd-(z,y) backward-weights kernel ITSELF (launch counter DRAM_K3_WGRAD_WZY, on its own) against an fp64
+    reference and against the z-only kernel (DRAM_WGRAD_NO_WZY=1, read per call): two lazy sources with DIFFERENT per-sample
+    coefficients, a concat boundary at 16 channels, D = 4 (two boxes per z column: the shortest the raw-plane ring serves),
+    W = 16 (one box per row), N = 3; a cropped second source whose window starts at x % 4 != 0 and whose rows are 19 floats (its
+    16-byte LDS-DMA pieces are then only dword aligned in global memory -- the kernel drops border pieces by explicit
+    out-of-range offsets, not by alignment, unlike the forward kernel's descriptor-range padding: wgrad_wzy.inc); base
+    pointers 4 bytes off 16-byte alignment.  This pins that dword-aligned 16-byte LDS-DMA is something the kernel may rely on."""
+    from dram_amd import functional as HF
+    from dram_amd import _lib
+    N, C1, C2, Co, (D, H, W), extra, lazy, off = case
+    Ci = C1 + C2
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+
+    def place(t, shift_bytes):          # a device copy whose base pointer is `shift_bytes` off a 16-byte boundary
+        store = torch.empty(t.numel() + 4, device=DEV)
+        v = store[shift_bytes // 4:shift_bytes // 4 + t.numel()].view_as(t)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == shift_bytes
+        return v
+    x1 = place(torch.randn(N, C1, D, H, W, generator=g(61)), off)
+    x2 = dev(torch.randn(N, C2, D + extra[0], H + extra[1], W + extra[2], generator=g(62))) if C2 else None
+    crop = tuple(int(np.ceil(e / 2)) for e in extra) if C2 else (0, 0, 0)
+    dy = place(torch.randn(N, Co, D, H, W, generator=g(63)), off)
+    coef1 = dev(torch.rand(N * C1 * 2, generator=g(64)) + 0.25) if lazy else None          # per (sample, channel): all different
+    coef2 = dev(torch.rand(N * C2 * 2, generator=g(65)) - 0.3) if (lazy and C2) else None
+    assert "wgrad_wzy" in HF.conv_wgrad_kernel_name(N, (D, H, W), Co, C1, C2, lazy=lazy)
+
+    def run(wzy):
+        if wzy:
+            os.environ.pop("DRAM_WGRAD_NO_WZY", None)
+        else:
+            os.environ["DRAM_WGRAD_NO_WZY"] = "1"
+        try:
+            dw = torch.full((Co, Ci, 3, 3, 3), float("nan"), device=DEV)
+            ws = torch.empty(max(16, _lib.lib.dram_conv3d_k3_wgrad_ws_bytes(N, Ci, Co, D, H, W)), dtype=torch.uint8, device=DEV)
+            d2 = (0, 0, 0) if x2 is None else tuple(x2.shape[2:])
+            before = HF.conv_launch_counts()
+            _lib.call("dram_conv3d_k3_wgrad_fused", p(x1), C1, p(coef1), 1, p(x2), C2, p(coef2), 1, *d2, *crop, p(dy), p(dw),
+                      p(ws), ws.numel(), N, Co, D, H, W, st)
+            torch.cuda.synchronize()
+            delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
+            assert delta[HF.K3_WGRAD_WZY] == (1 if wzy else 0) and sum(delta) == 1, (case, wzy, delta)
+        finally:
+            os.environ.pop("DRAM_WGRAD_NO_WZY", None)
+        return dw
+
+    def act(t, cf):
+        if cf is None:
+            return t.double()
+        c = cf.view(t.shape[0], t.shape[1], 2).double()
+        return torch.relu(t.double() * c[:, :, 0, None, None, None] + c[:, :, 1, None, None, None])
+    xin = act(x1, coef1)
+    if C2:
+        xin = torch.cat([xin, act(x2[:, :, crop[0]:crop[0] + D, crop[1]:crop[1] + H, crop[2]:crop[2] + W], coef2)], 1)
+    wr = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(xin.cpu(), wr, None, padding=1).backward(dy.double().cpu())
+    a, b = run(True), run(False)
+    check(a, wr.grad, f"wgrad (z,y) {case}", tol=2e-5)
+    check(b, wr.grad, f"wgrad z-only {case}", tol=2e-5)
 
 
 def test_direct_conv_kernels_still_agree():

@@ -75,6 +75,33 @@ def test_kernel_choice_queries():
     assert len(counts) == HF.K3_KINDS and all(c >= 0 for c in counts)
 
 
+def test_fwd_choice_depends_on_the_source_but_the_partial_count_does_not():
+    """A (z,y)-shaped forward launch whose source the (z,y) kernel refuses (a base pointer off 16-byte alignment; a cropped
+    skip whose window starts at x % 4 != 0 or whose rows are not multiples of 16 bytes) runs the z-only kernel ON THE SAME
+    32x4x2 BOXES: dram_conv3d_k3_stats_parts(shape) stays what the launch writes (round-3 advisor finding: at 56x32x56 the
+    z-only kernel would otherwise pick 8x16 boxes, 1568 partials against the 1792 the buffer was sized for)."""
+    import ctypes
+    from dram_amd import _lib
+
+    def name(dhw, co, ci, **src):
+        buf = ctypes.create_string_buffer(96)
+        kind = _lib.lib.dram_conv3d_k3_fwd_choice_src(ci, co, *dhw, co, 0, 0, 0, 0, 1, src.get("c2", 0), src.get("d2", 0),
+                                                      src.get("h2", 0), src.get("w2", 0), src.get("ox", 0), src.get("mis", 0),
+                                                      buf, len(buf))
+        assert kind >= 0
+        return kind, buf.value.decode()
+
+    dhw = (56, 32, 56)
+    parts = _lib.lib.dram_conv3d_k3_stats_parts(64, 64, *dhw)
+    assert parts == 2 * 8 * 28 * 4                                       # 32x4x2 boxes, 4 partials each
+    assert name(dhw, 64, 64) == (2, "conv3d_k3_fwd_wzy_kernel")
+    assert name(dhw, 64, 64, c2=32, d2=56, h2=32, w2=56, ox=0) == (2, "conv3d_k3_fwd_wzy_kernel")
+    for src in (dict(mis=1), dict(c2=32, d2=58, h2=35, w2=62, ox=3), dict(c2=32, d2=56, h2=32, w2=58, ox=0)):
+        assert name(dhw, 64, 64, **src) == (1, "conv3d_k3_fwd_wz_kernel<32, 4, 2, true>"), src
+    # a shape the (z,y) kernel does not serve keeps the z-only kernel's own box choice
+    assert name((56, 32, 56), 32, 64)[1] == "conv3d_k3_fwd_wz_kernel<8, 16, 1, true>"
+
+
 def test_cpu_tensors_fail_loudly():
     import parts
     blk = parts.ConvBlock5d([2, 3], [3, 4], 0, 3, False, 1, 0.0)

@@ -279,3 +279,31 @@ def test_dc3d_clean_fixture(golden_dir):
     for k, gref in grads.items():
         err = np.abs(params[k].grad.numpy() - gref).max() / np.abs(gref).max()
         assert err <= 1e-4, (k, err)
+
+
+def test_inference_tail_helpers(golden_dir):
+    """The numpy helpers around the model call of LesionSegTest.run (reference utils.py: windowing with its default span,
+    binary_cam's 8-bit view, find_crops, IOU, Dice -- oracle/make_golden.py:gen_infer_tail ran the reference's own
+    functions): the oracle's restatements are BIT-exact on them (integer / fp64 work).  The Otsu step of binary_cam is not
+    covered (skimage absent: unpinned)."""
+    z = _load(golden_dir, "infer_tail")
+    scan, lobe = z["scan"], z["lobe"]
+    w = O.windowing(scan, from_span=(-1150, 350), to_span=(0, 1))
+    assert w.dtype == np.float64 and np.array_equal(w, z["w_scan"])
+    view8 = O.windowing(w[lobe > 0], from_span=(0, 1), to_span=(0, 255)).astype(np.uint8)
+    assert np.array_equal(view8, z["view8"])
+    assert float(O.iou(z["a"] > 0, z["b"] > 0, 1e-5)) == float(z["iou"])
+    assert float(O.dice(z["a"] > 0, z["b"] > 0, 1e-5)) == float(z["dice"])
+    assert float(O.iou(np.zeros(3, bool), np.zeros(3, bool), 1e-5)) == float(z["iou_empty"]) == 1.0
+    for i in range(3):
+        c = z[f"crop{i}"]
+        sl = O.find_crops(lobe == int(c[0]), tuple(c[1:4]), c[4])
+        assert [s.start for s in sl] == list(c[5:8].astype(int)) and [s.stop for s in sl] == list(c[8:11].astype(int))
+    # the tail itself: with no vessel mask and a brightness threshold below every voxel the post mask equals the plain one
+    htp = (z["a"] * 0.7).astype(np.float32)
+    pred, post, th2 = O.lesion_post_process(htp, scan, lobe, None, 0.5)
+    assert np.array_equal(pred, z["a"]) and 0.0 <= th2 <= 1.0
+    assert np.array_equal(post, (z["a"] > 0) & (w > th2))
+    ves = z["b"]
+    _, post_v, _ = O.lesion_post_process(htp, scan, lobe, ves, 0.5)
+    assert np.array_equal(post_v, post & (ves == 0))
