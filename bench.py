@@ -61,9 +61,11 @@ def parse():
     ap.add_argument("--checkpoint-mode", default="stats", choices=["stats", "recompute"],
                     help="how checkpoint_layers flags are honoured (models.DC3D.checkpoint_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=90.0, help="budget for the CPU baseline sample (1 warm-up + 3 reps "
+                    "at 2x64^3 and at 1x128^3: ~60 s on 16 threads)")
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
-    ap.add_argument("--no-att", action="store_true", help="skip the attention-model step reported beside the headline")
+    ap.add_argument("--no-att", action="store_true", help="skip the side lines (reference-shape steps, inference step, "
+                    "measured ceilings) reported beside the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to rehearse the multi-rank path with several ranks on one GPU)")
     return ap.parse_args()
@@ -105,9 +107,10 @@ def host_cores():
 
 def cpu_baseline(budget_s):
     """The oracle's torch-CPU DC3D (same config, same kind of step: forward + backward, BatchNorm in training mode)
-    on this box's host cores, at the two reduced batches BASELINE.md section 3 names: 2 x 64^3 and 1 x 128^3.
-    `value` is the 1 x 128^3 figure (the metric's chunk shape); the 2 x 64^3 one rides along.  Bounded: one
-    warm-up + up to 3 reps at 64^3, then as many 128^3 reps (>= 1) as the rest of the budget allows."""
+    on this box's host cores, at the two reduced batches BASELINE.md section 3 names: 2 x 64^3 and 1 x 128^3, each as
+    1 warm-up + 3 timed repetitions, median reported.  `value` is the 1 x 128^3 figure (the
+    metric's chunk shape); the 2 x 64^3 one rides along.  Bounded: should a size overrun its share of `budget_s` it stops
+    after the repetition in flight and `sample` says how many were timed."""
     import torch
     from oracle import dram_oracle as O
     threads = host_cores()
@@ -117,7 +120,7 @@ def cpu_baseline(budget_s):
     for p in params.values():
         p.requires_grad_(True)
 
-    def measure(n, s, max_reps, budget, warm):
+    def measure(n, s, max_reps, budget):
         x = torch.rand(n, 1, s, s, s, generator=torch.Generator().manual_seed(1))
         gout = torch.randn(n, 1, s, s, s, generator=torch.Generator().manual_seed(2))
 
@@ -128,8 +131,7 @@ def cpu_baseline(budget_s):
             (out * gout).sum().backward()
 
         t_start = time.perf_counter()
-        if warm:
-            step()
+        step()                                                  # warm-up (threads, primitives, allocator)
         times = []
         while len(times) < max_reps:
             t0 = time.perf_counter()
@@ -141,22 +143,61 @@ def cpu_baseline(budget_s):
         return n * s ** 3 / times[len(times) // 2], len(times)
 
     t0 = time.perf_counter()
-    v64, r64 = measure(2, 64, 3, 0.4 * budget_s, True)
+    v64, r64 = measure(2, 64, 3, 0.25 * budget_s)
     left = max(1.0, budget_s - (time.perf_counter() - t0))
-    v128, r128 = measure(1, 128, 3, left, False)          # threads and primitives are warm from the 64^3 runs
+    v128, r128 = measure(1, 128, 3, left)
     return {"value": v128, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "value_2x64": v64,
-            "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd on {threads} threads: 1x1x128^3 median of {r128} "
-                      f"rep(s) (value); 2x1x64^3 median of {r64} reps after 1 warm-up (value_2x64)"}
+            "value_2x64": v64, "reps": {"1x128": r128, "2x64": r64}, "warmups": 1,
+            "sample": f"oracle torch-CPU DC3D(st_dram_ref, bn) fwd+bwd on {threads} threads: 1x1x128^3, median of {r128} "
+                      f"rep(s) after 1 warm-up (value); 2x1x64^3, median of {r64} rep(s) after 1 warm-up (value_2x64)"}
 
 
-def att_model_step(dev, n=10, size=80, steps=3):
+def measured_ceilings(dev):
+    """both peaks calibrated on THIS box, in this process, ~1 s: a 16-byte-per-lane copy of 1 GiB
+    (read + written bytes / time) and a register-only v_mfma_f32_32x32x2_f32 loop on every CU (csrc/calibrate.hip), each
+    bracketed by HIP events on the launch stream; best of 5 after a warm-up launch."""
+    import ctypes
+    import torch
+    from dram_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).zero_()
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    sink = torch.empty(cus * 512, dtype=torch.float32, device=dev)
+    flops = ctypes.c_double(0.0)
+
+    def best(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        out = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        return min(out)
+    ms_copy = best(lambda: _lib.call("dram_calibrate_hbm_copy", src.data_ptr(), dst.data_ptr(), n, st))
+    ms_mfma = best(lambda: _lib.call("dram_calibrate_mfma_f32", sink.data_ptr(), cus, 20000, ctypes.addressof(flops), st))
+    del src, dst, sink
+    torch.cuda.empty_cache()
+    return {"hbm_copy_tbs": 2.0 * n / (ms_copy * 1e-3) / 1e12, "mfma_f32_tflops": flops.value / (ms_mfma * 1e-3) / 1e12,
+            "how": f"1 GiB 16-byte-per-lane copy (read + write bytes / time) and a register-only v_mfma_f32_32x32x2_f32 loop "
+                   f"(8 accumulator tiles, 2 waves per SIMD, {cus} CUs): best of 5 launches each, HIP events on the launch stream"}
+
+
+def model_train_step(dev, kind, n=10, size=80, steps=3):
+    """One train step of the reference's own training shape -- TRAIN_BATCH_SIZE 10 chunks of RESAMPLE_SIZE 80^3
+    (st_dram_ref.py:37,41 / st_dram_ref_att.py:40-45) -- through the same engine and trainer as the headline:
+    kind 'dc3d' = DC3D(st_dram_ref), 'att' = DC3DATGeneric(st_dram_ref_att) (models.py:415-597, what process_pipeline.py loads)."""
     import torch
     import models
-    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL
+    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL, ST_DRAM_REF_MODEL
     from dram_amd.train_step import DataParallelTrainer, synthetic_batch
     torch.manual_seed(0)
-    m = models.DC3DATGeneric(**ST_DRAM_REF_ATT_MODEL)
+    m = models.DC3DATGeneric(**ST_DRAM_REF_ATT_MODEL) if kind == "att" else models.DC3D(**ST_DRAM_REF_MODEL)
     m.init(models.HeNorm(mode="fan_in"))
     m = m.to(dev).train()
     tr = DataParallelTrainer(m, torch.optim.Adam(m.parameters(), lr=1e-4))
@@ -168,9 +209,39 @@ def att_model_step(dev, n=10, size=80, steps=3):
         reg, seg = tr.step(b)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"model": "DC3DATGeneric st_dram_ref_att (attention grid 64^3, 18 neighbours)", "chunks": n, "chunk": [size] * 3,
+    name = "DC3DATGeneric st_dram_ref_att (attention grid 64^3, 18 neighbours)" if kind == "att" else "DC3D st_dram_ref"
+    return {"model": name, "chunks": n, "chunk": [size] * 3,
             "ms_per_step": 1e3 * dt, "voxels_per_s": n * size ** 3 / dt, "fused_engine": bool(m.fused),
             "reg": float(reg), "seg": float(seg)}
+
+
+def inference_step(dev, shape=(300, 512, 512), reps=3):
+    """BASELINE config 5: whole-scan per-lobe inference (dram_amd/inference.py: crop -> 80^3 -> model -> paste -> Otsu -> brightness
+    gate) of a synthetic 300 x 512 x 512 CT with five lobes, FULL-WIDTH DC3DATGeneric(st_dram_ref_att) in eval mode -- the model
+    process_pipeline.py:11 loads; scan, label map and vessel mask resident in HBM before the timed region."""
+    import numpy as np
+    import torch
+    import models
+    from dram_amd.configs import ST_DRAM_REF_ATT_MODEL
+    from dram_amd.inference import LobeInference, synthetic_ct
+    torch.manual_seed(0)
+    m = models.DC3DATGeneric(**ST_DRAM_REF_ATT_MODEL)
+    m.init(models.HeNorm(mode="fan_in"))
+    m = m.to(dev).eval()
+    scan, lobe, spacing = synthetic_ct(shape, (1.0, 0.7, 0.7), seed=7, n_lesions=20)
+    scan_d, lobe_d = torch.as_tensor(scan).to(dev), torch.as_tensor(lobe).to(dev)
+    vessel_d = torch.zeros_like(lobe_d)
+    inf = LobeInference(m, resample_size=80)
+    res = inf.run(scan_d, lobe_d, spacing, vessel=vessel_d)            # warm-up (first launches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = inf.run(scan_d, lobe_d, spacing, vessel=vessel_d)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"model": "DC3DATGeneric st_dram_ref_att, eval mode, full width", "scan": list(shape), "lobes": len(res["chunks"]),
+            "resample": [80] * 3, "ms_per_scan": 1e3 * dt, "scan_voxels_per_s": float(np.prod(shape)) / dt,
+            "lesion_ratio": res["lesion_ratio"], "mask_voxels": int(res["mask"].sum()), "mask_post_voxels": int(res["mask_post"].sum())}
 
 
 def launch_ranks(n):
@@ -367,18 +438,31 @@ def main():
         dist.barrier()
 
     cpu = None
+    cpu_note = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)
+    elif world > 1:
+        cpu_note = "the CPU baseline is timed on rank 0 at N = 1 only (bench contract): see the n_gpus = 1 line"
+    elif args.no_cpu_baseline:
+        cpu_note = "skipped (--no-cpu-baseline)"
 
-    # ---- outside the timed region and not part of `value`: the attention model that process_pipeline.py loads
-    # (DC3DATGeneric(st_dram_ref_att), reference models.py:415-597) at the reference's own training shape -- TRAIN_BATCH_SIZE 10
-    # chunks of RESAMPLE_SIZE 80^3 (st_dram_ref_att.py:40-45) -- through the same engine and trainer
-    att = None
+    # ---- outside the timed region and not part of `value` (N = 1 only): the ceilings measured on this box, the reference's own
+    # training shape (10 x 80^3) with DC3D(st_dram_ref) and with the attention model process_pipeline.py loads, and config 5
+    att = ref_shape = infer = ceilings = None
     ck_mode = model.checkpoint_mode
+    peak_alloc = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak_res = torch.cuda.max_memory_reserved() / 2 ** 30
     if rank == 0 and world == 1 and not args.no_att:
         del trainer, opt, model, batch, losses
         torch.cuda.empty_cache()
-        att = att_model_step(dev)
+        ceilings = measured_ceilings(dev)
+        ref_shape = model_train_step(dev, "dc3d")
+        att = model_train_step(dev, "att")
+        torch.cuda.empty_cache()
+        infer = inference_step(dev)
+    if roofline is not None and ceilings is not None:
+        roofline["frac_of_measured"] = roofline["achieved"] / ceilings["mfma_f32_tflops"]
+        roofline["peak_measured"] = ceilings["mfma_f32_tflops"]
 
     if rank == 0:
         flops_per_voxel = 5415936.0     # fwd+bwd algorithmic FLOPs per input voxel
@@ -398,8 +482,8 @@ def main():
                        "chunks_per_gpu": args.chunks, "chunk": [args.size] * 3, "micro_batch": args.micro,
                        "parallelism": f"dp{world}"},
             "per_gpu_voxels_per_s": value / world,
-            "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "peak_hbm_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30,      # what torch's allocator holds at the peak
+            "peak_hbm_allocated_gb": peak_alloc,
+            "peak_hbm_reserved_gb": peak_res,      # what torch's allocator holds at the peak of the timed steps
             "hbm_total_gb": torch.cuda.get_device_properties(dev).total_memory / 2 ** 30,
             # whole step against the fp32 peak: executed = what the kernels issue (conv FLOPs x 2/3 resp. 4/9 where the
             # Winograd kernels run: every layer but the first), algorithmic = the direct-conv count of SURVEY 8(d)
@@ -410,8 +494,11 @@ def main():
             "loss": {"reg": [l[0] for l in loss_hist], "seg": [l[1] for l in loss_hist],
                      "param_abs_sum_after": psum, "finite": finite},
             "dist": dist_info,
-            "attention_model_step": att,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "ceilings_measured": ceilings,
+            "reference_shape_step": ref_shape, "attention_model_step": att, "inference_step": infer,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_note": cpu_note, "kernels": kernels,
+            "kernels_note": "a kernel's time is that of its C-ABI call on the launch stream (HIP events around the call): a "
+                            "backward-weights entry includes its fixed-order slab reduction (0.07 % of it)",
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -111,6 +111,9 @@ SIGNATURES = {
     "dram_masked_smooth_l1_bwd": (I, [P, P, P, P, P, P, P, I, I, L, P]),
     "dram_affine_sample_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_affine_sample_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    # measured ceilings (bench.py)
+    "dram_calibrate_hbm_copy": (I, [P, P, Z, P]),
+    "dram_calibrate_mfma_f32": (I, [P, I, I, P, P]),
 }
 
 

@@ -467,10 +467,19 @@ def _trilinear_bwd(dy, in_shape):
     return dx
 
 
-def backward(model, record, gout, need_dx):
-    """Returns ({parameter: gradient}, dx or None).  `gout`: gradient w.r.t. the dense output."""
+def backward(model, record, gout, need_dx, sink=None):
+    """Returns ({parameter: gradient}, dx or None).  `gout`: gradient w.r.t. the dense output.
+    `sink(parameter, gradient) -> bool`: called as soon as a parameter's gradient is final -- the head first, then stage by
+    stage from the last up-block to the first down-block, each right after its backward-weights launch -- so that a
+    data-parallel trainer can start that gradient's all-reduce while the rest of backward still runs
+    (train_step.DataParallelTrainer); a gradient the sink takes (True) is left out of the returned dict."""
     st = _stream()
-    grads = {}          # parameter -> gradient
+
+    class _Grads(dict):         # parameter -> gradient (what the sink does not take)
+        def __setitem__(self, p, g):
+            if sink is None or not sink(p, g):
+                dict.__setitem__(self, p, g)
+    grads = _Grads()
     gact = {}           # id(Lazy) -> dense gradient w.r.t. the ACTIVATED tensor (accumulated over its consumers)
     g = HF._chk(gout, "DC3D grad_output", 5)
     root = record[0][1]
@@ -655,7 +664,7 @@ class DC3DFusedFn(Function):
         if record is None:
             raise RuntimeError("DC3DFusedFn: backward without a recorded forward")
         try:
-            grads, dx = backward(model, record, gout, ctx.needs_input_grad[2])
+            grads, dx = backward(model, record, gout, ctx.needs_input_grad[2], sink=getattr(model, "grad_sink", None))
         finally:
             ctx.record = None        # free the saved activations now, not when the graph dies
         out = [None, None, dx if ctx.needs_input_grad[2] else None]

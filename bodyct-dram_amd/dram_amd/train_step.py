@@ -103,7 +103,7 @@ class DeviceIntRegRefineLoss:
 class DataParallelTrainer:
     """One optimisation step of DC3D on this rank's chunks, optionally as micro-batches with
     gradient accumulation, and -- when torch.distributed is initialised -- an all-reduce of the gradients in a
-    few large flat buckets before the optimiser step.
+    few large flat buckets, OVERLAPPED with backward, before the optimiser step.
 
     What the step computes is rank-count independent: it is the reference's loss on the GLOBAL batch
     (all ranks' chunks), evaluated shard by shard.  `reg_loss` is a sum over samples (metrics.py:177), so
@@ -113,9 +113,16 @@ class DataParallelTrainer:
     and W ranks with one shard each reproduce one rank running the same shards as micro-batches
     (tests/test_gpu_dp.py).
 
-    xGMI is point-to-point (7 links/GPU): the 65 MB of fp32 gradients take < 1 ms as a ring
-    all-reduce, against a multi-second step, so the buckets are reduced right after the last
-    backward; per-rank BatchNorm statistics (the reference's default "bn") need no exchange."""
+    Overlap: the fused engine's backward (dram_amd/engine.py) hands every parameter gradient to
+    `grad_sink` the moment it is final -- the head first, then stage by stage, each right after its backward-weights launch.
+    During the LAST micro-batch's backward the trainer writes it (plus what earlier micro-batches accumulated) straight into
+    its slot of a persistent flat bucket and starts that bucket's asynchronous all-reduce as soon as the bucket is complete:
+    RCCL runs it on its own stream beside the remaining backward kernels (the largest gradient, us_modules.0's 768 -> 256
+    filter, 21 MB, is ready after ~45 % of backward).  What autograd delivers outside the engine (per-op path, the attention
+    module of DC3DATGeneric) joins after backward.  xGMI is point-to-point (7 links/GPU): the 65 MB take < 1 ms as a ring
+    all-reduce against a multi-second step, so this hides little here -- it is the stated design and costs nothing.
+    Per-rank BatchNorm statistics (the reference's default "bn") need no exchange.  `p.grad` of every parameter is a view
+    into its bucket after the step (no per-step torch.cat, no copy back)."""
 
     def __init__(self, model, optimizer, loss_fn=None, loss_factors=(2.0, 1.0), bucket_mb=32):
         self.model, self.opt = model, optimizer
@@ -124,6 +131,16 @@ class DataParallelTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = self._make_buckets(bucket_mb * (1 << 20))
+        self._slot = {}                            # parameter -> (bucket index, offset)
+        for bi, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._slot[p] = (bi, off)
+                off += p.numel()
+        self._flat = [None] * len(self.buckets)    # persistent flat buffers (allocated at the first reduction)
+        self._filled = [set() for _ in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self.overlapped_buckets = 0                # (diagnostics) buckets whose all-reduce started inside the last backward
 
     def _make_buckets(self, cap_bytes):
         buckets, cur, size = [], [], 0
@@ -137,24 +154,61 @@ class DataParallelTrainer:
             buckets.append(cur)
         return buckets
 
+    # ---- gradient exchange
+    def _flat_of(self, bi):
+        if self._flat[bi] is None:
+            p0 = self.buckets[bi][0]
+            self._flat[bi] = torch.empty(sum(p.numel() for p in self.buckets[bi]), dtype=p0.dtype, device=p0.device)
+        return self._flat[bi]
+
+    def _begin(self):
+        for f in self._filled:
+            f.clear()
+        self._works = [None] * len(self.buckets)
+        self.overlapped_buckets = 0
+
+    def _deposit(self, p, g):
+        """Write the final gradient of `p` (g, plus whatever p.grad accumulated before; g None: p.grad alone, or zeros) into
+        its bucket slot; start the bucket's all-reduce when it is complete."""
+        bi, off = self._slot[p]
+        view = self._flat_of(bi)[off:off + p.numel()]
+        if g is not None and p.grad is not None:
+            torch.add(p.grad.reshape(-1), g.reshape(-1), out=view)
+        elif g is not None:
+            view.copy_(g.reshape(-1))
+        elif p.grad is not None:
+            if p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad.reshape(-1))
+        else:
+            view.zero_()                            # a parameter without a gradient on this rank still takes part
+        self._filled[bi].add(p)
+        if len(self._filled[bi]) == len(self.buckets[bi]):
+            self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _grad_sink(self, p, g):
+        """engine.backward's sink during the last micro-batch's backward (see the class docstring)."""
+        if p not in self._slot or p in self._filled[self._slot[p][0]]:
+            return False
+        self._deposit(p, g)
+        return True
+
     def allreduce_gradients(self):
-        """Sum the gradients over the ranks (see the class docstring for why a sum)."""
+        """Sum the gradients over the ranks (see the class docstring for why a sum): every bucket that backward has not
+        already sent is completed from p.grad and sent now; then wait, and point p.grad at the reduced slots."""
         if self.world == 1:
             return
-        works = []
-        for bucket in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-        for work, flat, bucket in works:
-            work.wait()
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                if p not in self._filled[bi]:
+                    self._deposit(p, None)
+        for bi, bucket in enumerate(self.buckets):
+            self._works[bi].wait()
             off = 0
             for p in bucket:
                 n = p.numel()
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[off:off + n].view_as(p))
+                p.grad = self._flat[bi][off:off + n].view_as(p)
                 off += n
+        self._begin()
 
     def step(self, batch, micro_batch=None, global_batch=None):
         """Returns the (detached, device) loss components of this rank's batch: reg summed, seg weighted by
@@ -164,14 +218,24 @@ class DataParallelTrainer:
         n_glob = int(global_batch) if global_batch else n * self.world
         mb = n if not micro_batch else min(micro_batch, n)
         self.opt.zero_grad(set_to_none=True)
+        self._begin()
         tot_reg = tot_seg = None
-        for lo in range(0, n, mb):
+        starts = list(range(0, n, mb))
+        for lo in starts:
             b = batch.micro(lo, min(n, lo + mb))
             dense, refined = self.model(b.images, b.lobes)
             reg, seg = self.loss_fn(dense, b, refined=None if refined is dense else refined)
             share = len(b) / n_glob
             loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * share
-            loss.backward()
+            overlap = self.world > 1 and lo == starts[-1]
+            if overlap:
+                self.model.grad_sink = self._grad_sink
+            try:
+                loss.backward()
+            finally:
+                if overlap:
+                    self.model.grad_sink = None
+                    self.overlapped_buckets = sum(w is not None for w in self._works)
             tot_reg = reg.detach() if tot_reg is None else tot_reg + reg.detach()
             tot_seg = seg.detach() * share if tot_seg is None else tot_seg + seg.detach() * share
         self.allreduce_gradients()

@@ -451,6 +451,14 @@ int dram_affine_sample_fwd(const float* x, float* y, const float* theta12, int N
 int dram_affine_sample_bwd(const float* dy, float* dx, const float* theta12, int N, int C, int D, int H, int W,
                            void* stream);
 
+/* ---- measured ceilings of the device ("calibrate both peaks on the box with a copy kernel and an FMA
+ * loop"); no reference counterpart.  Both only launch: the caller brackets them with HIP events on `stream`.
+ * dram_calibrate_hbm_copy: dst = src, 16 bytes per lane (2 x nbytes of HBM traffic).
+ * dram_calibrate_mfma_f32: a register-only v_mfma_f32_32x32x2_f32 loop, `blocks` x 8 waves x iters x 32 MFMAs; *flops (may be
+ *   NULL) receives the launch's FLOP count; sink: blocks * 512 floats. ---- */
+int dram_calibrate_hbm_copy(const void* src, void* dst, size_t nbytes, void* stream);
+int dram_calibrate_mfma_f32(float* sink, int blocks, int iters, double* flops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,7 +63,7 @@ def _worker(rank, world, port, backend, norm, out):
     reg, seg = tr.step(_shard(rank))
     torch.cuda.synchronize()
     out[rank] = {"params": {k: v.detach().cpu() for k, v in m.named_parameters()},
-                 "reg": float(reg), "seg": float(seg)}
+                 "reg": float(reg), "seg": float(seg), "overlapped": tr.overlapped_buckets, "buckets": len(tr.buckets)}
     dist.destroy_process_group()
 
 
@@ -90,6 +90,10 @@ def test_two_rank_step_equals_one_rank_micro_batched_step(backend):
                     f"({refused[0] if refused else 'init failed'}); the multi-GPU path is the driver's SCALE run")
     assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert set(res) == {0, 1}
+    # the all-reduce of (nearly) every bucket started INSIDE backward, from the engine's gradient sink: only the bucket that
+    # holds the first layer's parameters can complete with the last gradient of backward
+    for r in range(world):
+        assert res[r]["overlapped"] >= res[r]["buckets"] - 1 >= 3, (res[r]["overlapped"], res[r]["buckets"])
 
     # one rank, the two shards as two micro-batches of the same global batch
     m = _model(norm).cuda().train()
@@ -158,3 +162,27 @@ def test_rccl_all_reduce_path_single_rank():
     tr.step(_shard(0))
     for k, v in m.named_parameters():
         assert torch.equal(v.detach().cpu(), res["params"][k]), k
+
+
+def test_bench_two_ranks_over_gloo_as_a_child_process():
+    """`python bench.py --gpus 2` as the driver starts it (it launches its two ranks itself: torch.distributed.run children), over
+    gloo because the test box has one GPU: the multi-rank code path of the benchmark -- process group, per-rank data, gradient
+    all-reduce overlapped with backward, MAX over ranks of the time, the JSON line with `roofline` and a `cpu_baseline` field
+    (null + reason for N > 1) -- must run and report finite losses for both ranks' shards."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--chunks", "2",
+                        "--size", "32", "--micro", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-att"],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["dist"]["ranks_seen"] == 2 and line["dist"]["backend"] == "gloo"
+    assert line["loss"]["finite"] and len(line["loss"]["reg"]) == 1
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 32 ** 3 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert line["roofline"] is not None and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1.0
+    assert line["cpu_baseline"] is None and "N = 1" in line["cpu_baseline_note"]

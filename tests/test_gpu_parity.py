@@ -320,7 +320,8 @@ def test_conv3d_k3_fused_forward_source_fallback_keeps_its_partials():
 
 WGRAD_WZY_CASES = [
     # N, C1, C2, Cout, (D, H, W), skip shape beyond (D, H, W), lazy, bytes off alignment of x1 / dy
-    (3, 16, 16, 64, (4, 6, 16), (2, 3, 4), True, 0),      # review case: two lazy sources, concat boundary at 16, D = 4, W = 16, N = 3
+    (3, 16, 16, 80, (4, 6, 16), (2, 3, 4), True, 0),      # review case: two lazy sources, concat boundary at 16, D = 4, W = 16, N = 3
+                                                          # (80 output channels: the z-only kernel of the A/B needs its 128 x 16 tile for that boundary)
     (2, 32, 16, 72, (4, 4, 16), (2, 3, 3), True, 0),      # crop window at x offset 2 (ceil(3/2)), rows of 19 floats: unaligned 16-byte pieces
     (2, 32, 16, 72, (4, 4, 16), (2, 3, 3), False, 0),     # ... plain operands
     (2, 16, 0, 64, (6, 4, 32), (0, 0, 0), True, 4),       # x and dy 4 bytes off a 16-byte boundary, lazy
