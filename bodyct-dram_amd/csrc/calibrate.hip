@@ -9,14 +9,31 @@
 // Both only launch; bench.py brackets them with HIP events on the launch stream.  No result is consumed: `sink` receives one
 // float per thread so that the loop is not removed.
 #include "common.h"
+#include <stdlib.h>
 
 namespace dram {
 
 typedef float calib_f32x16 __attribute__((ext_vector_type(16)));
+typedef float calib_f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void calibrate_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+// U independent 16-byte loads per thread in flight before the first store; one pass, no loop (a block = 256 x U x 16 B)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void calibrate_copy_kernel(const calib_f32x4* __restrict__ src, calib_f32x4* __restrict__ dst, size_t n16) {
+    const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    calib_f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n16) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n16) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i);
+            else dst[i] = v[u];
+        }
+    }
 }
 
 __global__ __launch_bounds__(512, 1) void calibrate_mfma_kernel(float* __restrict__ sink, int iters, float a0, float b0) {
@@ -48,9 +65,16 @@ extern "C" int dram_calibrate_hbm_copy(const void* src, void* dst, size_t nbytes
     DRAM_REQUIRE(src && dst && nbytes >= 16 && nbytes % 16 == 0, "calibrate_hbm_copy: need two buffers of a multiple of 16 bytes");
     DRAM_REQUIRE(((((unsigned long long)src) | ((unsigned long long)dst)) & 15ull) == 0, "calibrate_hbm_copy: buffers must be 16-byte aligned");
     const size_t n16 = nbytes / 16;
-    const size_t want = (n16 + 255) / 256;
-    const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
-    hipLaunchKernelGGL(calibrate_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n16);
+    static const int variant = getenv("DRAM_CALIB_COPY_VARIANT") ? atoi(getenv("DRAM_CALIB_COPY_VARIANT")) : 0;   // (sweeps only)
+    const int U = (variant & 3) == 1 ? 1 : ((variant & 3) == 2 ? 8 : 4);
+    const size_t blocks = (n16 + (size_t)256 * U - 1) / ((size_t)256 * U);
+    DRAM_REQUIRE(blocks <= 0x7fffffffull, "calibrate_hbm_copy: buffer too large");
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = (variant & 4) != 0;
+    if (U == 1) { if (nt) hipLaunchKernelGGL((calibrate_copy_kernel<1, true>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); else hipLaunchKernelGGL((calibrate_copy_kernel<1, false>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); }
+    else if (U == 8) { if (nt) hipLaunchKernelGGL((calibrate_copy_kernel<8, true>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); else hipLaunchKernelGGL((calibrate_copy_kernel<8, false>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); }
+    else { if (nt) hipLaunchKernelGGL((calibrate_copy_kernel<4, true>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); else hipLaunchKernelGGL((calibrate_copy_kernel<4, false>), grid, blk, 0, st, (const calib_f32x4*)src, (calib_f32x4*)dst, n16); }
     return check_launch("calibrate_hbm_copy");
 }
 

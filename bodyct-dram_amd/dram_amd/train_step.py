@@ -131,11 +131,11 @@ class DataParallelTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = self._make_buckets(bucket_mb * (1 << 20))
-        self._slot = {}                            # parameter -> (bucket index, offset)
+        self._slot = {}                            # id(parameter) -> (bucket index, offset)
         for bi, bucket in enumerate(self.buckets):
             off = 0
             for p in bucket:
-                self._slot[p] = (bi, off)
+                self._slot[id(p)] = (bi, off)
                 off += p.numel()
         self._flat = [None] * len(self.buckets)    # persistent flat buffers (allocated at the first reduction)
         self._filled = [set() for _ in self.buckets]
@@ -165,12 +165,11 @@ class DataParallelTrainer:
         for f in self._filled:
             f.clear()
         self._works = [None] * len(self.buckets)
-        self.overlapped_buckets = 0
 
     def _deposit(self, p, g):
         """Write the final gradient of `p` (g, plus whatever p.grad accumulated before; g None: p.grad alone, or zeros) into
         its bucket slot; start the bucket's all-reduce when it is complete."""
-        bi, off = self._slot[p]
+        bi, off = self._slot[id(p)]
         view = self._flat_of(bi)[off:off + p.numel()]
         if g is not None and p.grad is not None:
             torch.add(p.grad.reshape(-1), g.reshape(-1), out=view)
@@ -181,13 +180,13 @@ class DataParallelTrainer:
                 view.copy_(p.grad.reshape(-1))
         else:
             view.zero_()                            # a parameter without a gradient on this rank still takes part
-        self._filled[bi].add(p)
+        self._filled[bi].add(id(p))
         if len(self._filled[bi]) == len(self.buckets[bi]):
             self._works[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
 
     def _grad_sink(self, p, g):
         """engine.backward's sink during the last micro-batch's backward (see the class docstring)."""
-        if p not in self._slot or p in self._filled[self._slot[p][0]]:
+        if id(p) not in self._slot or id(p) in self._filled[self._slot[id(p)][0]]:
             return False
         self._deposit(p, g)
         return True
@@ -199,7 +198,7 @@ class DataParallelTrainer:
             return
         for bi, bucket in enumerate(self.buckets):
             for p in bucket:
-                if p not in self._filled[bi]:
+                if id(p) not in self._filled[bi]:
                     self._deposit(p, None)
         for bi, bucket in enumerate(self.buckets):
             self._works[bi].wait()
@@ -219,6 +218,7 @@ class DataParallelTrainer:
         mb = n if not micro_batch else min(micro_batch, n)
         self.opt.zero_grad(set_to_none=True)
         self._begin()
+        self.overlapped_buckets = 0
         tot_reg = tot_seg = None
         starts = list(range(0, n, mb))
         for lo in starts:

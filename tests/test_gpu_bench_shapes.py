@@ -237,12 +237,20 @@ def test_benchmark_batch_of_64_replicated_chunks(norm, monkeypatch):
 def test_full_width_batchnorm_distinct_chunks_sliced_vs_per_op(monkeypatch):
     """The hole the replicated-chunk test leaves (round-3 review): with 64 IDENTICAL samples any mis-pairing of per-sample
     data -- statistics partials of the wrong slice, a sample offset that lands on sample 0, lazy coefficients of another
-    sample -- still gives the right answer.  Here 8 DISTINCT 128^3 chunks go through DC3D(st_dram_ref, 'bn') at full width
-    with every activated tensor lazy, no upsampled tensor kept and every up-stage forced into ragged slices of 3 + 3 + 2
-    samples (BatchNorm statistics finalised once over all slices' partials, backward-weights summed over slices, lazy
-    backward-weights with per-sample coefficients), against the per-op path (one autograd node per op of the reference,
-    the path the reference's block goldens pin): outputs, EVERY gradient and the BatchNorm buffers to 1e-4, biases away from
-    the ReLU threshold; the (z,y) kernels counted on their own."""
+    sample -- still gives the right answer.  Here 8 DISTINCT 128^3 chunks go through DC3D(st_dram_ref, 'bn') at full width,
+    three ways:
+      (p) the per-op path (one autograd node per op of the reference: what the reference's block goldens pin);
+      (w) the fused engine, every activated tensor lazy (per-sample coefficients on load in forward, backward-weights,
+          pool, upsample, head), no upsampled tensor kept, whole batch per launch;
+      (s) the same with every up-stage forced into ragged slices of 3 + 3 + 2 samples (BatchNorm statistics finalised once
+          over all slices' partials, backward-weights summed over slices, d(upsampled) never whole).
+    (s) vs (w): every gradient to 5e-5 -- the only difference is the order in which three slices' dW are summed (measured:
+    2e-5 on us_modules.2's first filter, 3e-6 on the other two sliced filters, 0 elsewhere).  (w) and (s) vs (p): outputs to
+    2e-5, every gradient and BatchNorm buffer to 1e-4 -- except the norm parameters of us_modules.0's second stage at 2e-4: its
+    gradient reaches it through four BatchNorm backwards whose (g - mean g) cancels strongly under the positive test gradient,
+    and the two paths' statistics differ in the last bit (measured 1.00e-4 / 7.5e-5 there, identical for (w) and (s): the
+    difference is between summation trees of the statistics, not between samples or slices).  Biases away from the ReLU
+    threshold; the (z,y) kernels counted on their own."""
     from dram_amd import engine
     from dram_amd import functional as HF
     torch.cuda.empty_cache()
@@ -258,10 +266,16 @@ def test_full_width_batchnorm_distinct_chunks_sliced_vs_per_op(monkeypatch):
     o_ref, g_ref, _ = _device_step(model, x, gout, fused=False)
     buf_ref = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
     torch.cuda.empty_cache()
-    model.load_state_dict(sd0)
     monkeypatch.setattr(engine, "MEMORY_MODE", "manual")
     monkeypatch.setattr(engine, "MATERIALISE_BELOW", 0.0)
     monkeypatch.setattr(engine, "KEEP_UPSAMPLED_BELOW", 0.0)
+    # (w) whole batch per launch
+    model.load_state_dict(sd0)
+    monkeypatch.setattr(engine, "SLICE_UPSAMPLED_ABOVE", 1.0)
+    o_w, g_w, _ = _device_step(model, x, gout, fused=True)
+    assert engine.LAST_PLAN.sliced_stages == 0
+    # (s) slices of 3 + 3 + 2
+    model.load_state_dict(sd0)
     slices = engine._slices
 
     def three_at_a_time(inp, n, budget):
@@ -273,16 +287,21 @@ def test_full_width_batchnorm_distinct_chunks_sliced_vs_per_op(monkeypatch):
     o_got, g_got, delta = _device_step(model, x, gout, fused=True)
     plan = engine.LAST_PLAN
     assert plan.sliced_stages == 3, plan.sliced_stages              # us0, us1, us2 each as (0,3) (3,6) (6,8)
-    # 14 forward + 13 backward-data launches, the up-stages' first convs three times each; first layer and the 16^3 level aside
+    # 11 forward + 10 backward-data launches on the (z,y) kernel, the up-stages' first convs three times each
     assert delta[HF.K3_FWD_WZY] >= 16 + 12, delta
     assert delta[HF.K3_WGRAD_WZY] >= 13 + 6 and delta[HF.K3_WGRAD_WZ_LAZY] + delta[HF.K3_WGRAD_WZ] == 0, delta
-    assert _rel(o_got, o_ref) <= 2e-5, _rel(o_got, o_ref)
+    # (s) vs (w)
+    assert torch.equal(o_got, o_w)
+    sw = {k: _rel(g_got[k], g_w[k]) for k in g_w}
+    assert max(sw.values()) <= 5e-5, {k: v for k, v in sw.items() if v > 5e-5}
+    # (w), (s) vs (p)
     worst_sample = max(_rel(o_got[n], o_ref[n]) for n in range(N))
-    errs = {k: _rel(g_got[k], g_ref[k]) for k in g_ref}
-    print(f"\nDC3D(st_dram_ref, bn) 8 distinct 128^3 chunks, lazy + slices of 3/3/2 vs per-op: out {_rel(o_got, o_ref):.2e} "
-          f"(worst sample {worst_sample:.2e}), worst gradient {max(errs.values()):.2e}")
-    assert worst_sample <= 5e-5, worst_sample
-    bad = {k: v for k, v in errs.items() if v > 1e-4}
-    assert not bad, bad
+    assert worst_sample <= 2e-5, worst_sample
+    for name, g in (("whole", g_w), ("sliced", g_got)):
+        errs = {k: _rel(g[k], g_ref[k]) for k in g_ref}
+        print(f"\nDC3D(st_dram_ref, bn) 8 distinct 128^3 chunks, lazy, {name} vs per-op: worst sample out {worst_sample:.2e}, "
+              f"worst gradient {max(errs.values()):.2e} ({max(errs, key=errs.get)}); sliced vs whole {max(sw.values()):.2e}")
+        bad = {k: v for k, v in errs.items() if v > (2e-4 if k.startswith("us_modules.0.conv_blocks.1.1.") else 1e-4)}
+        assert not bad, (name, bad)
     for k, v in buf_ref.items():
         assert _rel(model.state_dict()[k].double(), v.double()) <= 1e-5, k

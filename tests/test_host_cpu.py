@@ -258,3 +258,16 @@ def test_engine_applicability_and_footprint():
     # 295.5 channel-planes at full resolution per sample: 32+64 | (64+128)/8 | (128+256)/64 | (256+512)/512 | 512/64 | 256/8 | 128
     assert abs(gib(1) - 295.5 * 128 ** 3 * 4 / 2 ** 30) < 1e-6
     assert 2.2 * gib(32) < 0.62 * 288 < 2.2 * gib(64)        # "speed" up to 32 chunks, "tight" for the whole batch of 64
+
+
+def test_isa_has_no_store_data_hazard():
+    """The hazard class behind round 3's silent data fault -- a store of more than 64 bits whose data registers the NEXT VALU
+    instruction overwrites; hipcc 7.2 leaves the pair unseparated when a buffer store's soffset is an SGPR, and on gfx950 the
+    store then picks up the new value (conv3d_k3_fwd_c1w_kernel) -- must not occur in ANY kernel of the
+    built library.  scripts/isa_hazards.py disassembles every gfx950 code object of libdram_hip.so (host tools only); the scanner
+    itself was checked against a build with the kernel's pinned wait states removed: 56 hits, all in that kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(ROOT, "scripts", "isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(os.path.join(ROOT, "bodyct-dram_amd", "libdram_hip.so")) == 0
