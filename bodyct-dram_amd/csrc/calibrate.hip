@@ -1,8 +1,8 @@
 // Measured ceilings of the device the library runs on ("calibrate both peaks on the box with a copy
 // kernel and an FMA loop and quote achieved/peak against the measured ceilings as well as the vendor ones"), gfx950.
 //
-//   dram_calibrate_hbm_copy   dst[i] = src[i], 16 bytes per lane and instruction, grid-stride: the streaming rate a kernel of
-//                             this library can reach when it reads and writes every byte once (bytes moved = 2 x nbytes).
+//   dram_calibrate_hbm_copy   dst[i] = src[i], one non-temporal 16-byte load + store per thread: the streaming rate a kernel
+//                             can reach when it reads and writes every byte once (bytes moved = 2 x nbytes).
 //   dram_calibrate_mfma_f32   a register-only loop of v_mfma_f32_32x32x2_f32 on 8 independent accumulator tiles, two waves
 //                             per SIMD on every CU: the issue rate of the exact-fp32 matrix instruction the conv kernels are
 //                             built on (FLOPs = blocks x 8 waves x iters x 32 MFMAs x 4096).
@@ -65,7 +65,9 @@ extern "C" int dram_calibrate_hbm_copy(const void* src, void* dst, size_t nbytes
     DRAM_REQUIRE(src && dst && nbytes >= 16 && nbytes % 16 == 0, "calibrate_hbm_copy: need two buffers of a multiple of 16 bytes");
     DRAM_REQUIRE(((((unsigned long long)src) | ((unsigned long long)dst)) & 15ull) == 0, "calibrate_hbm_copy: buffers must be 16-byte aligned");
     const size_t n16 = nbytes / 16;
-    static const int variant = getenv("DRAM_CALIB_COPY_VARIANT") ? atoi(getenv("DRAM_CALIB_COPY_VARIANT")) : 0;   // (sweeps only)
+    // Measured on MI355X (scripts/calib_sweep.py, 1 GiB, read + written bytes / time): one 16-byte load per thread, non-temporal:
+    // 6.64 TB/s; the same with default cache policy 6.24; four loads in flight per thread 5.68 / 6.21 (nt); eight 4.33 / 4.38.
+    static const int variant = getenv("DRAM_CALIB_COPY_VARIANT") ? atoi(getenv("DRAM_CALIB_COPY_VARIANT")) : 5;   // (sweeps only)
     const int U = (variant & 3) == 1 ? 1 : ((variant & 3) == 2 ? 8 : 4);
     const size_t blocks = (n16 + (size_t)256 * U - 1) / ((size_t)256 * U);
     DRAM_REQUIRE(blocks <= 0x7fffffffull, "calibrate_hbm_copy: buffer too large");

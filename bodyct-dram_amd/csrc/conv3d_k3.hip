@@ -1007,21 +1007,44 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_fwd_wz_kernel(ConvArgs a) {
 // Filters: wzy[t = 16 kx + xi][chunk][kh][Cout][kk] (channel = 4 chunk + 2 kk + kh), zero-filled to whole chunks by
 // pack_weights_wzy_kernel, so that a chunk's [48][2][64][2] tile is a lane-linear copy.
 // Serves Cout % 64 == 0, Cin >= 8, volumes that 32x4x2 boxes cover well (fwd_choice); everything else: the z-only kernel.
-struct FwdWzyGeom {
-    static constexpr int HX = 34;
-    static constexpr int XI_STRIDE = 2 * HX * 2;        // floats per transformed plane: [y pair][hx][kk]
+// Two box shapes (template parameter BX), the same 256 voxels, 8 waves and LDS budget:
+//   BX = 32: 32 x positions x 2 y pairs x 1 z pair: a wave's 32 MFMA columns = the 32 x positions of ONE y pair (128-byte rows);
+//   BX = 16: 16 x positions x 2 y pairs x 2 z pairs: a wave's 32 columns = 16 x positions of the TWO y pairs of one z pair -- for
+//            volumes that 32-wide boxes pad (the reference's own 80^3 chunks: the widths 80 / 40 / 20 of its pyramid are covered
+//            by 16-wide boxes to 100 / 83 / 62 %, by 32-wide ones to 83 / 62 / 31 %; the 16^3 level of 128^3 chunks exactly).
+//            Transformed planes are laid out [z pair][hx][y pair][kk], so that the 32 columns of a wave are again 64 consecutive
+//            dwords (conflict-free ds_read_b64) and an x tap is a constant offset.  (16 x 8 rows x 1 z pair would need 10 raw
+//            rows of 4 planes: 2 KB more than the CU's LDS; 6 rows of 6 planes is less than the 32-wide box's raw stage and
+//            fetches 2.25 instead of 2.5 halo elements per output.)
+template <int BX>
+struct FwdWzyGeomT {
+    static_assert(BX == 32 || BX == 16, "box widths of the (z,y) kernel");
+    static constexpr int NZP = BX == 32 ? 1 : 2;        // z pairs of a box
+    static constexpr int BY = 4, BZ = 2 * NZP;          // rows / planes of a box
+    static constexpr int HX = BX + 2;
+    static constexpr int KXS = BX == 32 ? 2 : 4;        // floats between two x positions of a transformed plane
+    static constexpr int XI_STRIDE = 2 * NZP * HX * 2;  // floats per transformed plane: [y pair][hx][kk] / [z pair][hx][y pair][kk]
     static constexpr int KH_STRIDE = 16 * XI_STRIDE;    // per channel parity kh
     static constexpr int IN_STAGE = 2 * KH_STRIDE;      // 4352 floats
     static constexpr int WT_STRIDE = 2 * 64 * 2;        // per filter matrix t: [kh][co][kk]
     static constexpr int W_STAGE = 48 * WT_STRIDE;      // 12288 floats
     static constexpr int STAGE = IN_STAGE + W_STAGE;    // one stage: inputs, then filters
     static constexpr int WPASS = W_STAGE / 4 / 512;     // 16-byte slots per thread and chunk
-    // raw input rows as they come from memory (LDS-DMA, 16 bytes per lane): [ci 4][z plane 4][row 6][40 floats = x0 - 4 .. x0 + 35],
+    // raw input rows as they come from memory (LDS-DMA, 16 bytes per lane): [ci 4][z plane BZ + 2][row 6][BX + 8 floats = x0 - 4 ..
+    // x0 + BX + 3] (240 / 216 16-byte pieces per channel: four LDS-DMA instructions, the last one of 48 / 24 lanes),
     // double-buffered (the chunk after next lands while the next one is transformed)
-    static constexpr int RAW_ROW = 40, RAW_PLANE = 6 * RAW_ROW, RAW_CI = 4 * RAW_PLANE, RAW_STAGE = 4 * RAW_CI;
+    static constexpr int RAW_PLANES = BZ + 2, RAW_ROW = BX + 8, RAW_PCS = RAW_ROW / 4;
+    static constexpr int RAW_PLANE = 6 * RAW_ROW, RAW_CI = RAW_PLANES * RAW_PLANE, RAW_STAGE = 4 * RAW_CI;
+    static constexpr int RAW_PIECES = RAW_CI / 4, RAW_PL_PIECES = RAW_PLANE / 4;
+    static_assert(RAW_PIECES > 192 && RAW_PIECES <= 256, "four LDS-DMA instructions per channel");
     static constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + 2 * RAW_STAGE) * sizeof(float);
     static_assert(LDS_BYTES <= 160 * 1024, "one block per CU: the whole LDS");
+    // float index of position (z pair zp, y pair yp, halo column hx) inside a transformed plane
+    __host__ __device__ static constexpr int pos(int zp, int yp, int hx) {
+        return BX == 32 ? (yp * HX + hx) * 2 : (zp * HX + hx) * 4 + yp * 2;
+    }
 };
+using FwdWzyGeom = FwdWzyGeomT<32>;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -1038,9 +1061,10 @@ __device__ unsigned long long g_wzy_stamps[32];      // [0 .. 15]: waves 0-3, [1
 // One instantiation serves plain and fused launches (lazy operands / statistics are runtime-uniform options): a separate
 // plain instantiation measured 2-4 % SLOWER than this one run without the options (241 vs 251, 258 vs 269 TFLOP/s
 // direct-equivalent at 64->64 / 192->64, 128^3), so it was dropped.
-__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, int total_items) {
-    using G = FwdWzyGeom;
-    constexpr int HX = G::HX, XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE;
+template <int BX>
+__device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items) {
+    using G = FwdWzyGeomT<BX>;
+    constexpr int XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE, KXS = G::KXS;
     constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE, WPASS = G::WPASS;
     constexpr int SL0 = 7;         // first of the four iterations that carry the staging slices (8 measured the same)
     // Iterations in which the next chunk's loads are issued: the input patch right behind the barrier (it is wanted first, at
@@ -1083,16 +1107,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     const int s_ci = wave & 3;
     const bool st_extra = wave >= 4;
     const int e_q = lane & 3, e_r = (lane >> 2) & 3;
-    const int i_ty = lane >> 5;
-    const int i_hx = st_extra ? 32 + ((lane >> 4) & 1) : lane & 31;
-    // LDS float index of the lane's xi = 0 element (patch stagers) / of its one element xi = (q, r) (column stagers)
-    const int st_idx = (s_ci & 1) * KHS + (i_ty * HX + i_hx) * 2 + (s_ci >> 1) + (st_extra ? (4 * e_q + e_r) * XI : 0);
+    // (z pair, y pair, halo column) of the lane's patch (patch stagers: BX columns x 2 y pairs x NZP z pairs = 64 lanes) / of its
+    // FIRST element (column stagers: four patches -- (y pair 0 / 1) x (column BX / BX + 1) -- per pass of 64 lanes; BX = 16 has
+    // eight such patches: a second pass for z pair 1, ONE stage row (HX positions) further in LDS)
+    const int i_ty = st_extra ? lane >> 5 : (BX == 32 ? lane >> 5 : (lane >> 4) & 1);
+    const int i_tz = (st_extra || BX == 32) ? 0 : lane >> 5;
+    const int i_hx = st_extra ? BX + ((lane >> 4) & 1) : lane & (BX - 1);
+    constexpr int NEX = G::NZP;                    // elements per lane of a column stager
+    constexpr int EX_STEP = BX == 32 ? 0 : G::pos(1, 0, 0) - G::pos(0, 0, 0);
+    // LDS float index of the lane's xi = 0 element (patch stagers) / of its (first) element xi = (q, r) (column stagers)
+    const int st_idx = (s_ci & 1) * KHS + G::pos(i_tz, i_ty, i_hx) + (s_ci >> 1) + (st_extra ? (4 * e_q + e_r) * XI : 0);
     // B^T along one axis, across the four lanes i = 0..3 of that axis: out_i = sa_i v_i + sb_i v_t(i), t = (2, 2, 1, 1)
     const float e_saz = e_q == 3 ? -1.f : 1.f, e_sbz = (e_q & 1) ? 1.f : -1.f;
     const float e_say = e_r == 3 ? -1.f : 1.f, e_sby = (e_r & 1) ? 1.f : -1.f;
     const bool e_mid = e_r == 1 || e_r == 2;
     // per staged item (set_staging_item):
-    unsigned rowmask[4];           // all ones / zero: row inside the volume
+    unsigned rowmask[4];           // all ones / zero: row inside the volume (column stagers: [0], [1] = their one or two elements)
     int sg_z0 = 0, sg_row1 = 0, sg_row2 = 0;
     // ---- fetch role (every wave): the raw rows of channel c0 + (wave >> 1), half (wave & 1) of its 240 16-byte pieces
     // [plane 4][row 6][x piece 10], by two LDS-DMA instructions (64 + 56 lanes).  Per fetched item (set_fetch_item):
@@ -1111,9 +1141,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         int b = item;
         const int cot = k->co_tiles, nbx = k->nbx, nby = k->nby, nbz = k->nbz;
         co0 = (b % cot) * 64; b /= cot;
-        x0 = (b % nbx) * 32; b /= nbx;
+        x0 = (b % nbx) * BX; b /= nbx;
         y0 = (b % nby) * 4; b /= nby;
-        z0 = (b % nbz) * 2;
+        z0 = (b % nbz) * G::BZ;
         n = b / nbz;
     };
     // The whole pipeline is instantiated twice, for the patch stagers (waves 0-3) and the column stagers (waves 4-7), behind
@@ -1131,10 +1161,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             sg_row1 = n * kC1;
             sg_row2 = n * kC2 - kC1;
             const int gx = x0 - 1 + i_hx;
-            if (EXTRA) {             // one element per lane: its validity (plane included)
-                const int gy = y0 - 1 + 2 * i_ty + e_r, gz = z0 - 1 + e_q;
-                const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
-                rowmask[0] = ok ? 0xffffffffu : 0u;
+            if (EXTRA) {             // one element per lane (and pass): its validity (plane included)
+    #pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int gy = y0 - 1 + 2 * i_ty + e_r, gz = z0 - 1 + 2 * e + e_q;
+                    const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
+                    rowmask[e] = ok ? 0xffffffffu : 0u;
+                }
             } else {
     #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1156,8 +1189,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             const int oz = k->src.oz, oy = k->src.oy, ox = k->src.ox, H2 = k->src.H2, W2 = k->src.W2;
     #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c = 64 * i + lane;                        // (lanes >= 48 of the last instruction: masked off at issue)
-                const int pl = c / 60, row = (c % 60) / 10, xc = c % 10;
+                const int c = 64 * i + lane;                        // (lanes >= 48 / 24 of the last instruction: masked off at issue)
+                const int pl = c / G::RAW_PL_PIECES, row = (c % G::RAW_PL_PIECES) / G::RAW_PCS, xc = c % G::RAW_PCS;
                 const int gz = z0 - 1 + pl, gy = y0 - 1 + row, gx = x0 - 4 + 4 * xc;    // W % 4 == 0: a piece is inside or outside as a whole
                 const bool ok = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (unsigned)gz < (unsigned)D;
                 dv1[i] = ok ? 4u * (unsigned)((gz * H + gy) * W + gx) : OOB;
@@ -1168,7 +1201,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
         const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
         const int j = lane & 31, kh = lane >> 5;
-        const int bbase = kh * KHS + 8 * xh * XI + (ty * HX + j) * 2;
+        // column j of the wave's tile = x position j of y pair ty (BX = 32) / x position j % 16 of y pair j / 16 of z pair ty (BX = 16)
+        const int bbase = kh * KHS + 8 * xh * XI + (BX == 32 ? G::pos(0, ty, j) : G::pos(ty, j >> 4, j & 15));
         const int abase = IN_STAGE + 8 * xh * WTS + (kh * 64 + 32 * ct + j) * 2;
         // (measured: reading the two operand pairs of an iteration as four ds_read_b64 -- separate opaque bases, so that hipcc
         //  cannot merge them into ds_read2(st64)_b64 -- is 2-4 % SLOWER, although the merged form has half the LDS rate)
@@ -1208,15 +1242,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             const float* base = (first ? dg_base1 : dg_base2) + (size_t)(unsigned)(first ? ci : ci - C1) * sx;
             const __amdgpu_buffer_rsrc_t srd = make_rsrc(uniform_ptr(base), ci < Cin ? 4u * sx : 0u);
             float* dst = rawbuf + d_ci * G::RAW_CI + 256 * i;
-            if (i < 3 || lane < 48)
+            if (i < 3 || lane < G::RAW_PIECES - 192)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)dst, 16, (int)(first ? dv1[i] : dv2[i]), 0, 0, 0);
         };
         // the patch of the lane (waves 0-3) / its one element (waves 4-7) out of the raw buffer
         auto read_raw = [&](const float* rawbuf) {
             if (EXTRA) {
-                rin[0][0] = rawbuf[s_ci * G::RAW_CI + (e_q * 6 + 2 * i_ty + e_r) * G::RAW_ROW + 3 + i_hx];
+    #pragma unroll
+                for (int e = 0; e < NEX; ++e)
+                    rin[0][e] = rawbuf[s_ci * G::RAW_CI + ((2 * e + e_q) * 6 + 2 * i_ty + e_r) * G::RAW_ROW + 3 + i_hx];
             } else {
-                const float* pr = rawbuf + s_ci * G::RAW_CI + (2 * i_ty) * G::RAW_ROW + 3 + i_hx;
+                const float* pr = rawbuf + s_ci * G::RAW_CI + (2 * i_tz * 6 + 2 * i_ty) * G::RAW_ROW + 3 + i_hx;
     #pragma unroll
                 for (int q = 0; q < 4; ++q)
     #pragma unroll
@@ -1254,10 +1290,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
             if (half == 0) asm volatile("" : "+v"(lc_ab), "+v"(lc_lo));
             const float ca = lc_has ? lc_ab[0] : 1.f, cb = lc_has ? lc_ab[1] : 0.f;
             if (EXTRA) {             // the lane's one element (an element outside the volume was loaded as 0 and stays 0)
-                if (half == 0) {
-                    const float b1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[0]);
-                    const float l1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[0]);
-                    asm("v_fma_f32 %0, %1, %0, %2\n\tv_max_f32 %0, %0, %3" : "+v"(rin[0][0]) : "v"(ca), "v"(b1), "v"(l1));
+                if (half < NEX) {
+                    const float b1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cb) & rowmask[half]);
+                    const float l1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, lc_lo) & rowmask[half]);
+                    asm("v_fma_f32 %0, %1, %0, %2\n\tv_max_f32 %0, %0, %3" : "+v"(rin[0][half]) : "v"(ca), "v"(b1), "v"(l1));
                 }
                 return;
             }
@@ -1274,10 +1310,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     asm("v_fma_f32 %0, %1, %0, %2\n\tv_max_f32 %0, %0, %3" : "+v"(rin[q][r]) : "v"(ca), "v"(br[r]), "v"(lor[r]));
-            if (!(sg_z0 >= 1 && sg_z0 + 2 < D)) {            // a plane outside the volume (first / last pair only): zeros
+            if (!(sg_z0 >= 1 && sg_z0 + G::BZ < D)) {        // a plane outside the volume (first / last box along z only): zeros
     #pragma unroll
                 for (int q = 2 * half; q < 2 * half + 2; ++q) {
-                    const int gz = sg_z0 - 1 + q;
+                    const int gz = sg_z0 + 2 * i_tz - 1 + q;
                     if (!(gz >= 0 && gz < D)) {
     #pragma unroll
                         for (int r = 0; r < 4; ++r) rin[q][r] = 0.f;
@@ -1287,8 +1323,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         };
         auto transform_z = [&]() {                           // B^T d along z (in place)
             if (EXTRA) {             // across the quad's four lanes (planes): partner = quad_perm [2, 2, 1, 1]
-                const float t = dpp_mov<0x5A>(rin[0][0]);
-                rin[0][0] = fmaf(e_sbz, t, e_saz * rin[0][0]);
+    #pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const float t = dpp_mov<0x5A>(rin[0][e]);
+                    rin[0][e] = fmaf(e_sbz, t, e_saz * rin[0][e]);
+                }
                 return;
             }
     #pragma unroll
@@ -1299,12 +1338,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
         };
         auto transform_y_store = [&](float* o, int q) {      // (.) B along y, row xi_z = q -> LDS
             if (EXTRA) {             // across the four quads (rows) of a 16-lane DPP row; one store per lane
-                if (q == 0) {
-                    const float v = rin[0][0];
+                if (q < NEX) {              // (BX = 16: the second pass rides one slice later)
+                    const float v = rin[0][q];
                     const float t2 = dpp_mov<0x128>(v);                     // row_ror:8: the row two further (0 <-> 2, 1 <-> 3)
                     const float t1 = dpp_mov<0x1B>(dpp_mov<0x140>(v));      // row_mirror, quads reversed back: rows 1 <-> 2 (0 <-> 3)
                     const float t = e_mid ? t1 : t2;                        // partner row (2, 2, 1, 1)
-                    o[0] = fmaf(e_sby, t, e_say * v);
+                    o[q * EX_STEP] = fmaf(e_sby, t, e_say * v);
                 }
                 return;
             }
@@ -1358,7 +1397,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                 }
             __syncthreads();           // every wave has read: the stage may be filled again
             EP_STAMP(2)
-            const int gx = x0 + j, gz = z0 + xh, gy = y0 + 2 * ty;
+            const int gx = x0 + (BX == 32 ? j : (j & 15)), gz = z0 + (BX == 32 ? 0 : 2 * ty) + xh, gy = y0 + 2 * (BX == 32 ? ty : (j >> 4));
             const bool ok0 = gx < W && gz < D && gy < H;
             const bool ok1 = gx < W && gz < D && (gy + 1) < H;
             const int kCout = k->Cout;
@@ -1500,7 +1539,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
                     for (int h = 0; h < 2; ++h) {
                         const int u = 2 * it + h, kx = u >> 3, xi = u & 7;
                         av[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + abase + (16 * kx + xi) * WTS);
-                        bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + 2 * kx);
+                        bv[it & 1][h] = *reinterpret_cast<const f32x2*>(stage + bbase + xi * XI + KXS * kx);
                     }
                 }
     #pragma unroll
@@ -1553,6 +1592,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, i
     };
     if (st_extra) run(std::true_type{}); else run(std::false_type{});
 }
+
+__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy_kernel(ConvArgs a, int total_items) { fwd_wzy_body<32>(a, total_items); }
+__global__ __launch_bounds__(512, 1) void conv3d_k3_fwd_wzy16_kernel(ConvArgs a, int total_items) { fwd_wzy_body<16>(a, total_items); }
 
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -2503,9 +2545,12 @@ static int persistent_blocks() {       // one block per CU of the current device
     return cus[dev];
 }
 
+template <int BX>
 static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
+    using G = FwdWzyGeomT<BX>;
+    const auto kern = BX == 32 ? conv3d_k3_fwd_wzy_kernel : conv3d_k3_fwd_wzy16_kernel;
     static LdsAttrOnce lds_once;
-    if (const int rc = ensure_dynamic_lds((const void*)conv3d_k3_fwd_wzy_kernel, FwdWzyGeom::LDS_BYTES, lds_once, "conv3d_k3_fwd(wzy)")) return rc;
+    if (const int rc = ensure_dynamic_lds((const void*)kern, G::LDS_BYTES, lds_once, "conv3d_k3_fwd(wzy)")) return rc;
     a.co_tiles = a.Cout / 64;
     const int64_t total = (int64_t)nblk * a.co_tiles;
     if (total > 0x7fffffffLL) {
@@ -2514,20 +2559,21 @@ static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
     }
     const int64_t cus = persistent_blocks();
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    hipLaunchKernelGGL(conv3d_k3_fwd_wzy_kernel, dim3(grid), dim3(512), FwdWzyGeom::LDS_BYTES, st, a, (int)total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a, (int)total);
     return check_launch("conv3d_k3_fwd(wzy)");
 }
 
+template <int BX>
 static int launch_fwd_wzy(ConvArgs& a, hipStream_t st) {
-    a.nbx = cdiv(a.W, 32);
+    a.nbx = cdiv(a.W, BX);
     a.nby = cdiv(a.H, 4);
-    a.nbz = cdiv(a.D, 2);
+    a.nbz = cdiv(a.D, FwdWzyGeomT<BX>::BZ);
     const int64_t nblk = (int64_t)a.N * a.nbx * a.nby * a.nbz;
     if (nblk > 0x7fffffffLL) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    return launch_fwd_wzy_f(a, (unsigned)nblk, st);
+    return launch_fwd_wzy_f<BX>(a, (unsigned)nblk, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2623,43 +2669,75 @@ static bool use_wz(const ConvArgs& a) {
 }
 
 // Which forward kernel / box shape a shape gets (shared by the launch and by dram_conv3d_k3_stats_parts).
-// The Winograd-(z,y) kernel: whole 64-channel output tiles, enough input channels, and a volume that its 32x4x2 boxes
-// cover with little padding (it executes 2/3 of the z-only kernel's MFMAs: worth up to ~1.3x padding, taken at 1.2x).
-static bool use_wzy_shape(const ConvArgs& a) {       // what the SHAPE allows (dram_conv3d_k3_stats_parts sizes the partials by it)
+// The Winograd-(z,y) kernel: whole 64-channel output tiles, enough input channels, and a volume that one of its two boxes
+// covers with little padding (it executes 2/3 of the z-only kernel's MFMAs: worth up to ~1.3x padding):
+//   32 x 4 x 2 (128-byte rows: preferred) where it pads at most 1.2x and no more than the 16-wide box;
+//   16 x 4 x 4 where it pads less than that, or at most 1.2x, or at most 1.3x of what the z-only kernel's own best box pads
+//   (the 20^3 level of the reference's 80^3 chunks: 1.6 against 1.28 for 10x10 positions -- 38 against 46 MFMAs per output).
+// Returns the box width (32 / 16) or 0.
+static double wz_padding(int D, int H, int W);
+static int wzy_box(const ConvArgs& a) {       // what the SHAPE allows (dram_conv3d_k3_stats_parts sizes the partials by it)
     const bool off = getenv("DRAM_CONV_NO_WZY") != nullptr;     // (read per call: A/B tests toggle it inside one process)
-    if (off || !use_wz(a) || a.Cout % 64 != 0 || a.Cin < 8) return false;
-    if (a.dst.C2 > 0 && a.dst.C1 % 32 != 0) return false;                       // a wave's 32 channels: one destination tensor
+    if (off || !use_wz(a) || a.Cout % 64 != 0 || a.Cin < 8) return 0;
+    if (a.dst.C2 > 0 && a.dst.C1 % 32 != 0) return 0;                           // a wave's 32 channels: one destination tensor
     const int64_t dmax = (int64_t)a.D * a.H * a.W > (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2 ? (int64_t)a.D * a.H * a.W
                                                                                               : (int64_t)a.dst.D2 * a.dst.H2 * a.dst.W2;
-    if (dmax * 4 * 36 > 0xffffffffLL) return false;                             // ... behind one 32-bit descriptor
+    if (dmax * 4 * 36 > 0xffffffffLL) return 0;                                 // ... behind one 32-bit descriptor
     // input rows are fetched as aligned 16-byte pieces (LDS-DMA) behind one descriptor per channel
-    if (a.W % 4 != 0 || (int64_t)a.D * a.H * a.W * 4 >= (int64_t)OOB) return false;
-    const double padded = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2;
-    return padded <= 1.2 * (double)a.W * a.H * a.D;
+    if (a.W % 4 != 0 || (int64_t)a.D * a.H * a.W * 4 >= (int64_t)OOB) return 0;
+    const double vol = (double)a.W * a.H * a.D;
+    const double pad32 = (double)cdiv(a.W, 32) * 32 * cdiv(a.H, 4) * 4 * cdiv(a.D, 2) * 2 / vol;
+    const double pad16 = (double)cdiv(a.W, 16) * 16 * cdiv(a.H, 4) * 4 * cdiv(a.D, 4) * 4 / vol;
+    if (const char* f = getenv("DRAM_WZY_BX")) {                                // experiments / A-B tests only (read per call)
+        const int bx = atoi(f);
+        if (bx == 32) return pad32 <= 1.2 ? 32 : 0;
+        if (bx == 16) return 16;
+    }
+    if (pad32 <= 1.2 && pad32 <= pad16) return 32;
+    if (pad16 <= 1.2 || pad16 <= 1.3 * wz_padding(a.D, a.H, a.W)) return 16;
+    return 0;
 }
 // ... and what the SOURCE of one launch allows on top of that: 16-byte aligned bases, a cropped second source whose rows and
-// window start on 16-byte boundaries.  A launch that fails only this runs the z-only kernel on the SAME 32x4x2 boxes
-// (fwd_choice), so that the number of statistics partials stays a function of the shape alone.
+// window start on 16-byte boundaries.  A launch that fails only this runs the z-only kernel instead -- on the 32x4 positions of
+// the 32-wide box, on 16x8 positions for the 16-wide one -- and the number of statistics partials the caller sizes its buffer
+// for (dram_conv3d_k3_stats_parts: a function of the shape alone) covers both; unused slots are zero-filled by the launch.
 static bool wzy_source_ok(const ConvArgs& a) {
     if ((((unsigned long long)a.src.p1) | ((unsigned long long)a.src.p2)) & 15ull) return false;
     if (a.src.p2 && (a.src.W2 % 4 != 0 || a.src.ox % 4 != 0 || (int64_t)a.src.D2 * a.src.H2 * a.src.W2 * 4 >= (int64_t)OOB)) return false;
     return true;
 }
-static bool use_wzy(const ConvArgs& a) { return use_wzy_shape(a) && wzy_source_ok(a); }
 
 struct FwdChoice {
     bool c1;            // first-layer kernel (Cin = 1, plain source and destination)
     bool c1w;           // ... its wide form (a lane owns four consecutive x: W % 4 == 0, W >= 96)
     bool wz;
     bool wzy;
+    int wzy_bx;         // box width of the (z,y) kernel (32 / 16)
     int box;            // index into the kernel family's box table
     int nbx, nby, nbz;  // boxes per sample
     int parts_per_box;  // statistics partials a box writes per row
+    int parts_cap;      // partial slots per row the caller provides for this SHAPE (>= what any launch of it writes)
 };
+// padding of the z-only kernel's best box: lane slots spent per voxel
+static int wz_best_box(int H, int W) {
+    int best = 0;
+    double best_cost = -1.0;
+    for (int i = 0; i < 4; ++i) {
+        const double cost = (double)cdiv(W, kFwdWzBoxes[i][0]) * cdiv(H, kFwdWzBoxes[i][1]) * 128.0;   // lane slots spent on a plane
+        if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
+}
+static double wz_padding(int D, int H, int W) {
+    const int b = wz_best_box(H, W);
+    return (double)cdiv(W, kFwdWzBoxes[b][0]) * cdiv(H, kFwdWzBoxes[b][1]) * 256.0 * cdiv(D, 2) / ((double)W * H * D);   // (a box: 128 positions x 2 planes)
+}
 static FwdChoice fwd_choice(const ConvArgs& a) {
     FwdChoice c;
     c.wz = use_wz(a);
-    c.wzy = use_wzy(a);
+    const int shape_bx = wzy_box(a);
+    c.wzy = shape_bx != 0 && wzy_source_ok(a);
+    c.wzy_bx = c.wzy ? shape_bx : 0;
     c.parts_per_box = 4;
     static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
     c.c1 = !direct && a.Cin == 1 && a.src.p2 == nullptr && a.dst.p2 == nullptr && a.coef1 == nullptr;
@@ -2668,33 +2746,23 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
         c.box = 0;
         c.parts_per_box = 16;           // (wave, row)
         c.nbx = cdiv(a.W, FwdC1WGeom::BX); c.nby = cdiv(a.H, FwdC1WGeom::BY); c.nbz = cdiv(a.D, FwdC1WGeom::BZ);
-        return c;
-    }
-    if (c.c1) {
+    } else if (c.c1) {
         c.box = 0;
         c.parts_per_box = 8;            // (wave, row group)
         c.nbx = cdiv(a.W, FwdC1Geom::BX); c.nby = cdiv(a.H, FwdC1Geom::BY); c.nbz = cdiv(a.D, FwdC1Geom::BZ);
-        return c;
-    }
-    if (c.wzy) {
+    } else if (c.wzy) {
         c.box = 0;
-        c.nbx = cdiv(a.W, 32); c.nby = cdiv(a.H, 4); c.nbz = cdiv(a.D, 2);
-        return c;
-    }
-    if (c.wz) {
+        c.nbx = cdiv(a.W, c.wzy_bx); c.nby = cdiv(a.H, 4); c.nbz = cdiv(a.D, c.wzy_bx == 32 ? 2 : 4);
+    } else if (c.wz) {
         // position boxes: the padded plane area, weighted by the lanes a box leaves idle (10x10 uses 100 of 128: the
         // 20^3 and 10^3 levels of the reference's 80^3 chunks fit it exactly)
         const int (*boxes2)[2] = kFwdWzBoxes;
-        int best = 0;
-        double best_cost = -1.0;
-        for (int i = 0; i < 4; ++i) {
-            const double cost = (double)cdiv(a.W, boxes2[i][0]) * cdiv(a.H, boxes2[i][1]) * 128.0;   // lane slots spent on a plane
-            if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
-        }
+        int best = wz_best_box(a.H, a.W);
         if (const char* f = getenv("DRAM_FWD_BX"))
             for (int i = 0; i < 4; ++i)
                 if (atoi(f) == boxes2[i][0]) best = i;
-        if (use_wzy_shape(a)) best = 0;         // the (z,y) kernel's boxes: refused for its source only (wzy_source_ok)
+        if (shape_bx == 32) best = 0;           // the (z,y) kernel's shape, refused for its source only (wzy_source_ok)
+        if (shape_bx == 16) best = 1;
         c.box = best;
         c.nbx = cdiv(a.W, boxes2[best][0]); c.nby = cdiv(a.H, boxes2[best][1]); c.nbz = cdiv(a.D, 2);
     } else {
@@ -2702,6 +2770,13 @@ static FwdChoice fwd_choice(const ConvArgs& a) {
         c.box = pick_box(a.D, a.H, a.W, boxes, 3, "DRAM_FWD_BX");
         c.nbx = cdiv(a.W, boxes[c.box][0]); c.nby = cdiv(a.H, boxes[c.box][1]); c.nbz = cdiv(a.D, boxes[c.box][2]);
     }
+    const int64_t produced = (int64_t)c.nbx * c.nby * c.nbz * c.parts_per_box;
+    int64_t cap = produced;
+    if (shape_bx == 16 && !c.c1) {               // either kernel of a 16-wide (z,y) shape: (z,y) on 16x4x4, z-only on 16x8x2 boxes
+        const int64_t zy = (int64_t)cdiv(a.W, 16) * cdiv(a.H, 4) * cdiv(a.D, 4) * 4, z = (int64_t)cdiv(a.W, 16) * cdiv(a.H, 8) * cdiv(a.D, 2) * 4;
+        cap = zy > z ? zy : z;
+    }
+    c.parts_cap = cap > 0x7fffffffLL ? 0 : (int)cap;
     return c;
 }
 
@@ -2721,7 +2796,7 @@ static int fwd_kernel_id(const ConvArgs& a, const FwdChoice& c, char* name, size
         snprintf(buf, sizeof(buf), c.c1w ? "conv3d_k3_fwd_c1w_kernel" : "conv3d_k3_fwd_c1_kernel");
     } else if (c.wzy) {
         kind = DRAM_K3_FWD_WZY;
-        snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wzy_kernel");
+        snprintf(buf, sizeof(buf), c.wzy_bx == 32 ? "conv3d_k3_fwd_wzy_kernel" : "conv3d_k3_fwd_wzy16_kernel");
     } else if (c.wz) {
         kind = DRAM_K3_FWD_WZ;
         snprintf(buf, sizeof(buf), "conv3d_k3_fwd_wz_kernel<%d, %d, %d, %s>", kFwdWzBoxes[c.box][0], kFwdWzBoxes[c.box][1], cot,
@@ -2739,8 +2814,13 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     const FwdChoice c = fwd_choice(a);
     g_launches[fwd_kernel_id(a, c, nullptr, 0)].fetch_add(1, std::memory_order_relaxed);
     if (a.stats) {
-        DRAM_REQUIRE(a.nparts == c.nbx * c.nby * c.nbz * c.parts_per_box, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, "
-                     "this shape produces %d (dram_conv3d_k3_stats_parts)", a.nparts, c.nbx * c.nby * c.nbz * c.parts_per_box);
+        // the caller's slots per row (dram_conv3d_k3_stats_parts) must hold what this launch writes; slots it leaves unused
+        // (a 16-wide (z,y) shape whose two kernels box the volume differently) are zero-filled: count 0, ignored by the combine
+        const int produced = c.nbx * c.nby * c.nbz * c.parts_per_box;
+        DRAM_REQUIRE(a.nparts >= produced, "conv3d_k3_fwd: statistics buffer sized for %d partials per row, this shape produces %d "
+                     "(dram_conv3d_k3_stats_parts)", a.nparts, produced);
+        if (a.nparts > produced)
+            (void)hipMemsetAsync(a.stats, 0, (size_t)a.N * a.Cout * a.nparts * 3 * sizeof(float), st);
     }
     if (c.c1) {
         a.nbx = c.nbx; a.nby = c.nby; a.nbz = c.nbz;
@@ -2756,7 +2836,7 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     }
     if (c.wzy) {
         a.wt += (size_t)63 * a.Cin * a.Cout;      // ... and the (z,y)-transformed ones follow those
-        return launch_fwd_wzy(a, st);
+        return c.wzy_bx == 32 ? launch_fwd_wzy<32>(a, st) : launch_fwd_wzy<16>(a, st);
     }
     if (c.wz) {
         a.wt += (size_t)27 * a.Cin * a.Cout;      // the transformed filters follow the direct ones in the packed buffer
@@ -2792,11 +2872,14 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
         static const bool direct = getenv("DRAM_CONV_DIRECT") != nullptr;
         const bool off = getenv("DRAM_WGRAD_NO_WZY") != nullptr;      // (read per call: A/B tests toggle it inside one process)
         const int cit = 1;
-        if (!direct && !off && W % 16 == 0 && H % 2 == 0 && D % 2 == 0 && D >= 4 && (C1 == 0 || C1 % (16 * cit) == 0)) {   // (D >= 4: two boxes per z column, the raw plane ring counts on it)
+        // 16-wide boxes along x, the last one of a row ragged where W % 16 != 0 (16-byte pieces: W % 4 == 0) as long as it pads at
+        // most 1.3x (24 x 1.3 MFMAs against the z-only kernel's 36 on exact boxes: the reference's 40^3 level pads 1.2x)
+        const bool wide_ok = W % 4 == 0 && cdiv(W, 16) * 16 * 10 <= W * 13;
+        if (!direct && !off && wide_ok && H % 2 == 0 && D % 2 == 0 && D >= 4 && (C1 == 0 || C1 % (16 * cit) == 0)) {   // (D >= 4: two boxes per z column, the raw plane ring counts on it)
             p.wzy = 1;
             p.cit = cit;
             p.bx = 16; p.by = 2; p.bz = 2;
-            p.nbx = W / 16; p.nby = H / 2; p.nbz = D / 2;
+            p.nbx = cdiv(W, 16); p.nby = H / 2; p.nbz = D / 2;
             p.nboxes = (int)((int64_t)N * p.nbx * p.nby * p.nbz);
             p.ci_tiles = cdiv(Cin, 16 * cit);
             p.co_tiles = cdiv(Cout, 64);
@@ -3059,9 +3142,7 @@ extern "C" int dram_conv3d_k3_stats_parts(int Cin, int Cout, int D, int H, int W
     if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     ConvArgs a = {};
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
-    const FwdChoice c = fwd_choice(a);
-    const int64_t parts = (int64_t)c.nbx * c.nby * c.nbz * c.parts_per_box;
-    return parts > 0x7fffffffLL ? 0 : (int)parts;
+    return fwd_choice(a).parts_cap;
 }
 
 // Which kernel a forward / backward-data call of this shape launches (the same fwd_choice the launch uses).  The plain query

@@ -617,6 +617,28 @@ __global__ __launch_bounds__(256) void norm_finalize_parts_kernel(const double* 
     }
 }
 
+// per channel {mean, M2} in fp64 over the N rows of the channel (BatchNorm), from the level-1 triples: what a cross-rank
+// combine (nn.SyncBatchNorm, parts.py:32-33) gathers -- the same layout dram_bn_stats writes
+__global__ __launch_bounds__(256) void bn_parts_moments_kernel(const double* __restrict__ part2, int groups, int N, int C,
+                                                               double expect_count, double* __restrict__ mean_m2) {
+    __shared__ double sh[12];
+    const int c = blockIdx.x;
+    const int64_t items = (int64_t)N * groups;
+    Moments m = {0.0, 0.0, 0.0};
+    for (int64_t it = threadIdx.x; it < items; it += 256) {
+        const int64_t n = it / groups;
+        const int g = (int)(it % groups);
+        const double* o = part2 + ((n * C + c) * groups + g) * 3;
+        m = chan_merge(m, Moments{o[0], o[1], o[2]});
+    }
+    m = block_merge_256(m, sh);
+    if (threadIdx.x == 0) {
+        const bool bad = m.n != expect_count;          // a partial went missing: poison instead of a silent bias
+        mean_m2[2 * c] = bad ? NAN : m.mean;
+        mean_m2[2 * c + 1] = bad ? NAN : m.m2;
+    }
+}
+
 static inline bool vec_ok(const void* p, int64_t S) { return (S % 4 == 0) && (((uintptr_t)p) % 16 == 0); }
 
 static int check_norm(const char* who, int kind, int G, int N, int C, int64_t S) {
@@ -847,6 +869,27 @@ extern "C" int dram_norm_finalize_parts(const float* parts, int nparts, const fl
     hipLaunchKernelGGL(norm_finalize_parts_kernel, dim3(nstat), dim3(256), 0, st, part2, groups, kind, N, C, Gk, gamma, beta,
                        eps, save_mean, save_rstd, rowcoef, running_mean, running_var, momentum, expect);
     return check_launch("norm_finalize_parts");
+}
+
+// This rank's per-channel {mean, M2} (fp64, interleaved like dram_bn_stats) from the conv epilogue's partials: the input of
+// the cross-rank Chan combine of "sbn" on the fused engine.  (Inverting save_rstd -- var = rstd^-2 - eps -- cancels for
+// channels whose variance is far below eps.)
+extern "C" int dram_bn_parts_stats(const float* parts, int nparts, double* mean_m2, int N, int C, int64_t S, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    DRAM_REQUIRE(parts && mean_m2 && ws && nparts > 0, "bn_parts_stats: null pointer");
+    int rc = check_norm("bn_parts_stats", DRAM_NORM_BATCH, 1, N, C, S);
+    if (rc) return rc;
+    DRAM_REQUIRE((int64_t)N * C <= 65535, "bn_parts_stats: N*C > 65535 rows not supported");
+    if (ws_bytes < dram_norm_parts_ws_bytes(N, C, nparts)) {
+        set_error("bn_parts_stats: workspace too small");
+        return DRAM_EWS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = parts_groups(nparts);
+    double* part2 = (double*)ws;
+    hipLaunchKernelGGL(parts_reduce_kernel, dim3(groups, N * C), dim3(256), 0, st, parts, part2, nparts, groups);
+    hipLaunchKernelGGL(bn_parts_moments_kernel, dim3(C), dim3(256), 0, st, part2, groups, N, C, (double)N * (double)S, mean_m2);
+    return check_launch("bn_parts_stats");
 }
 
 // y = act(rowcoef[row][0] * x + rowcoef[row][1]): materialises a lazily normalised tensor (the consumers without an

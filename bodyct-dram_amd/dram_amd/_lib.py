@@ -96,6 +96,7 @@ SIGNATURES = {
     "dram_conv3d_k3_launch_counts": (I, [P, I]),
     "dram_norm_parts_ws_bytes": (Z, [I, I, I]),
     "dram_norm_finalize_parts": (I, [P, I, P, P, P, P, P, P, P, F, F, I, I, I, I, L, P, Z, P]),
+    "dram_bn_parts_stats": (I, [P, I, P, I, I, L, P, Z, P]),
     "dram_bn_eval_coef": (I, [P, P, P, P, P, P, P, F, I, I, P]),
     "dram_row_affine_act": (I, [P, P, P, I, L, L, P]),
     "dram_maxpool3d_2_fwd_lazy": (I, [P, P, I, P, P, I, I, I, I, I, P]),

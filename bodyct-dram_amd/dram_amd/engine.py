@@ -166,22 +166,24 @@ def _sync_group(norm, use_batch):
     return True, norm.process_group
 
 
-def _sync_forward_stats(norm, group, mean, rstd, coef, count, rm, rv, eaf, N, Co, st):
+def _sync_forward_stats(norm, group, parts, nparts, ws, mean, rstd, coef, count, rm, rv, eaf, N, Co, S, st):
     """Cross-rank combine of a stage's batch statistics (what functional.SyncBatchNormFn.forward does for the per-op
-    path): all-gather of {mean, M2, count} per channel, Chan's formula in fp64, running statistics from the GLOBAL
-    moments, then mean / rstd / per-row {a, b} rewritten from them.  `mean`, `rstd` hold this rank's statistics on entry
-    (dram_norm_finalize_parts without running buffers).  Returns the global element count per channel."""
+    path): this rank's per-channel {mean, M2} in fp64 straight from the conv epilogue's partials (dram_bn_parts_stats -- not
+    from save_rstd, whose inversion rstd^-2 - eps cancels for channels with variance far below eps), all-gather, Chan's
+    formula in fp64, running statistics from the GLOBAL moments, then mean / rstd / per-row {a, b} written from them.
+    Returns the global element count per channel."""
     import torch.distributed as dist
     eps = float(norm.eps)
     dev = mean.device
-    var_l = rstd.double().pow(-2) - eps                      # this rank's biased variance
-    local = torch.cat([mean.double(), var_l * float(count), torch.tensor([float(count)], dtype=torch.float64, device=dev)])
+    local = torch.empty(2 * Co + 1, dtype=torch.float64, device=dev)
+    call("dram_bn_parts_stats", _p(parts), nparts, _p(local), N, Co, S, _p(ws), ws.numel(), st)
+    local[2 * Co] = float(count)
     world = dist.get_world_size(group)
     allst = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(allst, local, group=group)
     allst = torch.stack(allst)                               # [world, 2 Co + 1]
     cnt = allst[:, 2 * Co].view(world, 1)
-    means, m2s = allst[:, :Co], allst[:, Co:2 * Co]
+    means, m2s = allst[:, 0:2 * Co:2], allst[:, 1:2 * Co:2]
     total = cnt.sum()
     gmean = (means * cnt).sum(0) / total
     m2 = (m2s + cnt * (means - gmean) ** 2).sum(0)
@@ -273,11 +275,11 @@ def _conv_stage(conv, norm, inp, skip, training, record, plan):
     total = None
     if use_batch:
         ws = _ws(_lib.lib.dram_norm_parts_ws_bytes(N, Co, nparts), dev)
-        call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef),
-             None if sync else _p(rm), None if sync else _p(rv),
-             float(eaf), float(norm.eps), kind, groups, N, Co, S, _p(ws), ws.numel(), st)
         if sync:        # "sbn": the statistics span the ranks (two small exchanges per stage and direction)
-            total = _sync_forward_stats(norm, group, mean, rstd, coef, N * S, rm, rv, float(eaf), N, Co, st)
+            total = _sync_forward_stats(norm, group, parts, nparts, ws, mean, rstd, coef, N * S, rm, rv, float(eaf), N, Co, S, st)
+        else:
+            call("dram_norm_finalize_parts", _p(parts), nparts, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(coef), _p(rm), _p(rv),
+                 float(eaf), float(norm.eps), kind, groups, N, Co, S, _p(ws), ws.numel(), st)
     else:   # eval-mode BatchNorm: coefficients from the running statistics
         call("dram_bn_eval_coef", _p(gamma), _p(beta), _p(rm), _p(rv), _p(mean), _p(rstd), _p(coef), float(norm.eps), N, Co, st)
     out = Lazy(y, coef, relu=True)

@@ -233,7 +233,13 @@ class PCM(nn.Module):
     plus a term over sin/cos positional encodings, `build_geo_feature`) and the sum-normalised
     `PCM_SUM_MERGES` (cosine, heu1, heu2) and 'l2' for f_dim == 1 (the one width for which the reference's broadcast
     of [.., 1, f_dim] against [.., f_dim, edges] and the reshape at models.py:396 are defined; other widths raise
-    ValueError).  Unknown names raise NotImplementedError at call time, like the reference."""
+    ValueError).  Unknown names raise NotImplementedError at call time, like the reference.
+
+    Deliberate numerical deviation ('l2' only): the reference evaluates exp(-5 (theta - phi_e)^2) / sum_e exp(...)
+    (models.py:262-264) literally, which is 0 / 0 = NaN for a node all of whose edges underflow (|theta - phi| > ~4.2 in fp32).
+    Here the same ratio is computed as a softmax over the edges of 10 theta phi_e - 5 phi_e^2 (the common -5 theta^2 cancels,
+    the maximum is subtracted): algebraically identical, finite for saturated inputs
+    (tests/test_gpu_pcm.py::test_pcm_l2_merge_saturated_inputs_stay_finite).  Like all of PCM: parity unpinned (DGL absent)."""
 
     def __init__(self, pool_size, in_ch, g_ch, f_dim, geo_f_dim, g_dim, non_local_iter, k_size,
                  merge_type='l2', self_loop=True, connectivity=2, residual=False, p_enc_dim=32):

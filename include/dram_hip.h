@@ -405,6 +405,11 @@ int dram_norm_finalize_parts(const float* parts, int nparts, const float* gamma,
                              float* running_var, float momentum, float eps, int kind, int G, int N, int C,
                              int64_t S, void* ws, size_t ws_bytes, void* stream);
 
+/* this rank's per-channel {mean, M2} in fp64 (mean_m2[2c], [2c+1]: the layout of dram_bn_stats) from the same partials: what
+ * nn.SyncBatchNorm (parts.py:32-33) exchanges between ranks; ws as dram_norm_parts_ws_bytes */
+int dram_bn_parts_stats(const float* parts, int nparts, double* mean_m2, int N, int C, int64_t S, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* eval-mode BatchNorm: rowcoef (and save_mean / save_rstd) from the running statistics, no pass over a tensor */
 int dram_bn_eval_coef(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float* save_mean, float* save_rstd, float* rowcoef, float eps, int N, int C, void* stream);

@@ -66,6 +66,14 @@ CONV_CASES = [
     (2, 12, 64, 4, 12, 64, False),    # channel tail inside a chunk (12 = 3 chunks), two boxes along x, two samples
     (1, 64, 64, 3, 9, 70, True),      # W = 70: partial third box (padding 1.37 > 1.2 -> z-only kernel; the boundary of the rule)
     (1, 64, 192, 2, 4, 58, False),    # W = 58 (padding 1.10): partial second box through the (z,y) kernel, three channel tiles
+    # shapes the 16-wide boxes (16 x 4 x 4) of the (z,y) kernel serve -- the pyramid of the reference's 80^3 chunks and the 16^3 level:
+    (1, 64, 64, 8, 8, 16, False),     # one box per row, two z pairs per box, two boxes along z and y
+    (2, 16, 128, 8, 12, 40, True),    # W = 40: ragged third box along x; bias; forward only on (z,y) (backward-data has 16 output channels)
+    (1, 64, 64, 20, 20, 20, False),   # 20^3 (level 2 of an 80^3 chunk): ragged x box, five exact boxes along y and z
+    (1, 72, 64, 24, 24, 24, False),   # W = 24
+    (1, 64, 64, 6, 10, 16, False),    # D = 6, H = 10: half-empty last box along z and along y (padding 1.6, like the z-only kernel's own)
+    (1, 64, 64, 7, 12, 16, False),    # D = 7: the last box holds ONE valid plane of its second z pair... (padding 1.14)
+    (2, 12, 64, 4, 4, 16, False),     # a single box per sample, channel tail inside a chunk
 ]
 
 
@@ -135,6 +143,20 @@ def test_conv3d_k3_wzy_kernel_is_selected():
     assert "wz_kernel" in HF.conv_fwd_kernel_name((3, 9, 70), 64, 64)          # too much padding
     assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 32), 16, 64)          # 16 output channels
     assert HF.conv_fwd_kernel_name((128, 128, 128), 64, 192, fused=True) == "conv3d_k3_fwd_wzy_kernel"
+    # ... and its 16-wide boxes where 32-wide ones pad more (the widths 80 / 40 / 20 / 24 / 16)
+    for dhw, co, ci in (((8, 8, 16), 64, 64), ((8, 12, 40), 128, 16), ((20, 20, 20), 64, 64), ((24, 24, 24), 64, 72),
+                        ((7, 12, 16), 64, 64), ((4, 4, 16), 64, 12), ((80, 80, 80), 64, 192)):
+        assert HF.conv_fwd_kernel_name(dhw, co, ci) == "conv3d_k3_fwd_wzy16_kernel", dhw
+    # 16 x 12 x 8 for 16 x 10 x 6: padding 1.6 -- as much as the z-only kernel's own best box (16 x 8 positions) pads: (z,y)
+    assert HF.conv_fwd_kernel_name((6, 10, 16), 64, 64) == "conv3d_k3_fwd_wzy16_kernel"
+    assert "wz_kernel" in HF.conv_fwd_kernel_name((6, 8, 16), 64, 64)           # 1.33 against an exact z-only box
+    before = HF.conv_launch_counts()
+    x = dev(torch.randn(1, 64, 8, 8, 16, generator=g(33))).requires_grad_(True)
+    w = dev(torch.randn(64, 64, 3, 3, 3, generator=g(34)) * 0.05).requires_grad_(True)
+    HF.conv3d_k3(x, w).sum().backward()
+    torch.cuda.synchronize()
+    delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
+    assert delta[HF.K3_FWD_WZY] == 2 and delta[HF.K3_WGRAD_WZY] == 1 and sum(delta) == 3, delta
     # what a launch really does: forward (64 -> 128) and backward-data (128 -> 64) on the (z,y) kernel, backward-weights on
     # the transposed Winograd kernel
     before = HF.conv_launch_counts()
@@ -203,6 +225,13 @@ def test_conv3d_k3_wzy_concat_and_split():
     (2, 6, 10, 64, 4, 12, 32, True, True),       # ... with the source boundary inside a 4-channel chunk (raw rows: per-channel source)
     (1, 64, 0, 192, 8, 16, 32, False, True),     # statistics of a plain source, three channel tiles
     (3, 16, 0, 64, 2, 4, 32, True, True),        # one plane pair, one box per sample: items of three samples per block
+    # 16-wide boxes
+    (2, 12, 0, 64, 8, 8, 16, True, True),        # channel tail; two boxes along z and y
+    (1, 16, 0, 128, 20, 20, 20, True, True),     # 20^3: ragged x box; the slot count covers the z-only boxing too (zero-filled tail)
+    (1, 8, 8, 64, 8, 12, 40, True, True),        # virtual concat (crop window at x offset 4), W = 40
+    (2, 6, 10, 64, 7, 8, 16, True, True),        # odd D (a box with one valid plane in its second z pair), source boundary inside a chunk
+    (3, 16, 0, 64, 4, 4, 16, True, False),       # one box per sample
+    (1, 64, 0, 64, 24, 24, 24, False, True),     # W = 24, statistics of a plain source
 ])
 def test_conv3d_k3_wzy_fused(case):
     """Fused forward (normalise + ReLU on load, statistics epilogue) of the Winograd-(z,y) kernel through the C ABI:
@@ -326,6 +355,9 @@ WGRAD_WZY_CASES = [
     (2, 32, 16, 72, (4, 4, 16), (2, 3, 3), False, 0),     # ... plain operands
     (2, 16, 0, 64, (6, 4, 32), (0, 0, 0), True, 4),       # x and dy 4 bytes off a 16-byte boundary, lazy
     (1, 48, 0, 130, (4, 8, 16), (0, 0, 0), False, 4),     # ... plain, three co tiles with a tail
+    (2, 16, 16, 80, (4, 6, 40), (2, 3, 4), True, 0),      # W = 40 (the 40^3 level of an 80^3 chunk): ragged third box along x, lazy
+    (1, 32, 0, 64, (6, 4, 72), (0, 0, 0), False, 0),      # W = 72: four full boxes + half a box, plain
+    (1, 16, 0, 64, (4, 4, 28), (0, 0, 0), True, 0),       # W = 28: the second box holds 12 of its 16 columns
 ]
 
 

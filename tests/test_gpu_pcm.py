@@ -187,6 +187,32 @@ def test_pcm_l2_merge_matches_oracle(shape, self_loop, conn):
         assert err <= TOL * max(scale, 1e-30), (k, err, scale)
 
 
+def test_pcm_l2_merge_saturated_inputs_stay_finite():
+    """The one deliberate numerical deviation of merge_type 'l2' (round-3 advisor note): the reference forms
+    exp(-5 (theta - phi_e)^2) / sum_e exp(...) (models.py:262-264); when every edge of a node underflows (|theta - phi| > ~4.2 in
+    fp32) that is 0 / 0 = NaN.  The device path evaluates the same quantity as a softmax over the edges (the common term
+    -5 theta^2 cancels, the maximum is subtracted): finite weights that sum to 1 and equal the fp64 softmax of the logits --
+    the limit the reference's expression has just before it underflows.  Pinned here so that the behaviour is a decision."""
+    from dram_amd import functional as HF
+    shape = (4, 5, 6)
+    g = torch.Generator().manual_seed(21)
+    theta = torch.full((1, 1) + shape, 30.0) + torch.randn((1, 1) + shape, generator=g)
+    phi = torch.randn((1, 1) + shape, generator=g) * 2.0                     # |theta - phi| ~ 30: exp(-4500) = 0 even in fp64
+    offs = [tuple(int(v) for v in o) for o in O.pcm_offsets(3, 2, False)]
+    attn = HF.pcm_attention(theta.cuda(), phi.cuda(), offs, "l2").cpu().double()          # [B, E, D, H, W]
+    assert torch.isfinite(attn).all()
+    naive = torch.exp(-5.0 * (theta.double()[0, 0, 2, 2, 3] - phi.double()[0, 0, 2, 2, 4]) ** 2)
+    assert float(naive) == 0.0                                                # the reference's numerator underflows ...
+    # interior node (2, 2, 3): all 18 edges exist; weights = softmax_e(-5 (theta - phi_e)^2)
+    z, y, x = 2, 2, 3
+    logits = torch.tensor([-5.0 * (float(theta[0, 0, z, y, x]) - float(phi[0, 0, z + dz, y + dy, x + dx])) ** 2 for dz, dy, dx in offs],
+                          dtype=torch.float64)
+    want = torch.softmax(logits, 0)
+    got = attn[0, :, z, y, x]
+    assert abs(float(got.sum()) - 1.0) <= 1e-5
+    assert (got - want).abs().max().item() <= 1e-4 * want.max().item() + 1e-7
+
+
 def _oracle_pcm(p, cam, f, conn, self_loop, merge, iters, residual):
     return O.pcm_forward(p, cam, f, 3, conn, self_loop, merge, iters, residual)
 

@@ -94,6 +94,10 @@ def _engine_worker(rank, world, port, out):
                 if isinstance(mod, torch.nn.BatchNorm3d) and mod.weight is not None:
                     mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
                     mod.bias.copy_((torch.randint(0, 2, mod.bias.shape, generator=g).float() * 2 - 1) * 3.0)
+            # channel 0 of the first stage: variance ~1e-9, far below eps = 1e-5 (its statistics must come from the partials'
+            # M2, not from inverting rstd); momentum 1 on that layer so that running_var shows the batch variance itself
+            m.ds_modules[0].conv_blocks[0][0].weight[0] *= 3e-5
+            m.ds_modules[0].conv_blocks[0][1].momentum = 1.0
         return m.cuda().train()
 
     g = torch.Generator().manual_seed(13)
@@ -122,6 +126,10 @@ def _engine_worker(rank, world, port, out):
         for k, v in ref.state_dict().items():
             if "running" in k:
                 errs[k] = rel(m.state_dict()[k], v)
+        k0 = "ds_modules.0.conv_blocks.0.1.running_var"
+        tiny_ref, tiny_got = float(ref.state_dict()[k0][0]), float(m.state_dict()[k0][0])
+        assert 0.0 < tiny_ref < 1e-7, tiny_ref
+        errs["running_var of the tiny-variance channel"] = abs(tiny_got - tiny_ref) / tiny_ref
         bad = {k: e for k, e in errs.items() if not e <= 2e-4}
         ok = not bad
         if bad:

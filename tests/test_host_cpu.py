@@ -65,7 +65,12 @@ def test_kernel_choice_queries():
     # first layer
     assert HF.conv_fwd_kernel_name(S, 32, 1, fused=True) == "conv3d_k3_fwd_c1w_kernel"
     assert HF.conv_fwd_kernel_name((80, 80, 80), 32, 1, fused=True) == "conv3d_k3_fwd_c1_kernel"
-    assert HF.conv_fwd_kernel_name((16, 16, 16), 512, 256, fused=True) == "conv3d_k3_fwd_wz_kernel<16, 8, 2, true>"
+    # the 16^3 level of 128^3 chunks and the reference's own 80^3 pyramid (80 / 40 / 20): 16-wide (z,y) boxes; 10^3: z-only
+    assert HF.conv_fwd_kernel_name((16, 16, 16), 512, 256, fused=True) == "conv3d_k3_fwd_wzy16_kernel"
+    for s_, co_, ci_ in ((80, 64, 192), (40, 128, 384), (20, 256, 768)):
+        assert HF.conv_fwd_kernel_name((s_,) * 3, co_, ci_, fused=True) == "conv3d_k3_fwd_wzy16_kernel", s_
+    assert HF.conv_fwd_kernel_name((10, 10, 10), 512, 256, fused=True) == "conv3d_k3_fwd_wz_kernel<10, 10, 2, true>"
+    assert HF.conv_fwd_kernel_name((5, 7, 32), 128, 64) == "conv3d_k3_fwd_wz_kernel<32, 4, 2, false>"      # either box pads too much
     wz = HF.conv_wgrad_kernel_name(64, S, 64, 128, 64, lazy=True)
     assert wz in ("conv3d_k3_wgrad_wz_kernel<16, 2, 4, 2, true>", "conv3d_k3_wgrad_wzy_kernel<true>"), wz
     assert HF.conv_wgrad_kernel_name(64, S, 32, 1) == "conv3d_k3_wgrad_c1_kernel"
@@ -100,6 +105,11 @@ def test_fwd_choice_depends_on_the_source_but_the_partial_count_does_not():
         assert name(dhw, 64, 64, **src) == (1, "conv3d_k3_fwd_wz_kernel<32, 4, 2, true>"), src
     # a shape the (z,y) kernel does not serve keeps the z-only kernel's own box choice
     assert name((56, 32, 56), 32, 64)[1] == "conv3d_k3_fwd_wz_kernel<8, 16, 1, true>"
+    # a 16-wide (z,y) shape: its refused launches run the z-only kernel on 16x8 positions; the slot count covers both boxings
+    # (20^3: 2 x 5 x 5 (z,y) boxes against 2 x 3 x 10 z-only ones)
+    assert _lib.lib.dram_conv3d_k3_stats_parts(64, 64, 20, 20, 20) == 2 * 3 * 10 * 4
+    assert name((20, 20, 20), 64, 64) == (2, "conv3d_k3_fwd_wzy16_kernel")
+    assert name((20, 20, 20), 64, 64, mis=1) == (1, "conv3d_k3_fwd_wz_kernel<16, 8, 2, true>")
 
 
 def test_cpu_tensors_fail_loudly():
