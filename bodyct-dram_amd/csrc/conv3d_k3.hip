@@ -2873,8 +2873,9 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
         const bool off = getenv("DRAM_WGRAD_NO_WZY") != nullptr;      // (read per call: A/B tests toggle it inside one process)
         const int cit = 1;
         // 16-wide boxes along x, the last one of a row ragged where W % 16 != 0 (16-byte pieces: W % 4 == 0) as long as it pads at
-        // most 1.3x (24 x 1.3 MFMAs against the z-only kernel's 36 on exact boxes: the reference's 40^3 level pads 1.2x)
-        const bool wide_ok = W % 4 == 0 && cdiv(W, 16) * 16 * 10 <= W * 13;
+        // most 1.6x (measured at the reference's 40^3 level, 1.2x padding: 233 TFLOP/s direct-equivalent against 186 for the
+        // z-only kernel on exact boxes; the 20^3 level pads 1.6x: ~175 against the z-only kernel's 151 there)
+        const bool wide_ok = W % 4 == 0 && cdiv(W, 16) * 16 * 10 <= W * 16;
         if (!direct && !off && wide_ok && H % 2 == 0 && D % 2 == 0 && D >= 4 && (C1 == 0 || C1 % (16 * cit) == 0)) {   // (D >= 4: two boxes per z column, the raw plane ring counts on it)
             p.wzy = 1;
             p.cit = cit;

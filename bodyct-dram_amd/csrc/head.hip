@@ -214,6 +214,89 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_vec_kernel(const float* __r
     }
 }
 
+// Several output channels (the 1x1x1 "reshape" convs of DC3DATGeneric: 64 / 128 -> 8, models.py:488-494): the kernels above
+// walk the output channels in their OUTER loop and read x once per output channel -- right for the 64 -> 1 head, 8x the
+// traffic for 8 outputs (rocprofv3 of the attention-model step: 6.2 % of it, 0.5-2.4 ms per launch for 0.3 ms of bytes).
+// Here a block owns WM_VPB voxels of sample n, a tile of WM_CT input channels and a tile of WM_CO output channels: per pair of
+// float4 positions it loads the WM_CO dy and WM_CT x vectors ONCE (all in flight together), keeps the WM_CO x WM_CT sums per
+// thread in registers over the block's voxels, and reduces them across the block once at the end.  Same partial layout
+// (with its own, larger voxel tile), same fixed-order fp64 final sum.  grid (nblk, N, ci tiles * co tiles).
+constexpr int WM_CO = 8, WM_CT = 8;
+constexpr int WM_VPB = 8192;              // voxels per block: four rounds of two float4 per thread
+__global__ __launch_bounds__(256) void conv1x1_wgrad_multi_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  float* __restrict__ part, int Cin, int Cout, int64_t S,
+                                                                  int nblk, int ci_tiles, const float* __restrict__ coef, int relu) {
+    __shared__ float red[4][WM_CO * WM_CT + WM_CO];
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c0 = (blockIdx.z % ci_tiles) * WM_CT, o0 = (blockIdx.z / ci_tiles) * WM_CO;
+    const float lo = (coef && relu) ? 0.f : -INFINITY;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[WM_CO][WM_CT];
+    float gsum[WM_CO];
+#pragma unroll
+    for (int o = 0; o < WM_CO; ++o) {
+        gsum[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM_CT; ++k) acc[o][k] = 0.f;
+    }
+    float ca[WM_CT], cb[WM_CT];
+#pragma unroll
+    for (int k = 0; k < WM_CT; ++k) {
+        const int c = c0 + k < Cin ? c0 + k : Cin - 1;                     // (tail channels: loaded, not stored)
+        ca[k] = coef ? coef[2 * ((int64_t)n * Cin + c)] : 1.f;
+        cb[k] = coef ? coef[2 * ((int64_t)n * Cin + c) + 1] : 0.f;
+    }
+    for (int64_t e = (int64_t)blk * WM_VPB + 4 * tid; e < (int64_t)(blk + 1) * WM_VPB && e < S; e += 1024) {
+        float4 g[WM_CO], xv[WM_CT];
+#pragma unroll
+        for (int o = 0; o < WM_CO; ++o)
+            g[o] = o0 + o < Cout ? *reinterpret_cast<const float4*>(dy + ((int64_t)n * Cout + o0 + o) * S + e) : z4;
+#pragma unroll
+        for (int k = 0; k < WM_CT; ++k) {
+            const int c = c0 + k < Cin ? c0 + k : Cin - 1;
+            xv[k] = *reinterpret_cast<const float4*>(x + ((int64_t)n * Cin + c) * S + e);
+        }
+        if (coef) {       // the input is a RAW conv output: act(a*x + b) on load
+#pragma unroll
+            for (int k = 0; k < WM_CT; ++k) {
+                xv[k].x = fmaxf(fmaf(ca[k], xv[k].x, cb[k]), lo); xv[k].y = fmaxf(fmaf(ca[k], xv[k].y, cb[k]), lo);
+                xv[k].z = fmaxf(fmaf(ca[k], xv[k].z, cb[k]), lo); xv[k].w = fmaxf(fmaf(ca[k], xv[k].w, cb[k]), lo);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < WM_CO; ++o) {
+            gsum[o] += (g[o].x + g[o].y) + (g[o].z + g[o].w);
+#pragma unroll
+            for (int k = 0; k < WM_CT; ++k) {
+                float a = acc[o][k];
+                a = fmaf(g[o].x, xv[k].x, a); a = fmaf(g[o].y, xv[k].y, a); a = fmaf(g[o].z, xv[k].z, a); a = fmaf(g[o].w, xv[k].w, a);
+                acc[o][k] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < WM_CO; ++o) {
+#pragma unroll
+        for (int k = 0; k < WM_CT; ++k) {
+            const float v = wave_sum(acc[o][k]);
+            if (lane == 0) red[wv][o * WM_CT + k] = v;
+        }
+        const float gv = wave_sum(gsum[o]);
+        if (lane == 0) red[wv][WM_CO * WM_CT + o] = gv;
+    }
+    __syncthreads();
+    if (tid < WM_CO * WM_CT + WM_CO) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const bool is_bias = tid >= WM_CO * WM_CT;
+        const int o = is_bias ? tid - WM_CO * WM_CT : tid / WM_CT, k = is_bias ? 0 : tid % WM_CT;
+        if (o0 + o < Cout) {
+            float* prow = part + (((size_t)n * nblk + blk) * Cout + o0 + o) * (Cin + 1);
+            if (is_bias) { if (c0 == 0) prow[Cin] = v; }
+            else if (c0 + k < Cin) prow[c0 + k] = v;
+        }
+    }
+}
+
 // out[j] = sum over `count` partial vectors of length L: one 256-thread block per j, fp64, fixed order
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int count, int L,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int Cin,
@@ -372,10 +455,17 @@ static int conv1x1_bwd_run(const float* dy, const float* x, const float* coef, i
             set_error("conv3d_k1_bwd: workspace too small");
             return DRAM_EWS;
         }
-        const int nblk = (int)cdiv64(S, WG_VPB);
+        int nblk = (int)cdiv64(S, WG_VPB);
         float* part = (float*)ws;
         static_assert(WG_VPB == 2048, "conv1x1_wgrad_vec_kernel: two float4 per thread");
-        if ((S % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0 && getenv("DRAM_K1_WGRAD_SCALAR") == nullptr)
+        static_assert(WM_VPB % WG_VPB == 0, "the multi-output kernel's partials fit the workspace sized for WG_VPB");
+        const bool vec = (S % 4) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0 && getenv("DRAM_K1_WGRAD_SCALAR") == nullptr;
+        const int ci_tiles = cdiv(Cin, WM_CT), co_tiles = cdiv(Cout, WM_CO);
+        if (vec && Cout > 1 && ci_tiles * co_tiles <= 65535 && getenv("DRAM_K1_WGRAD_NOMULTI") == nullptr) {
+            nblk = (int)cdiv64(S, WM_VPB);
+            hipLaunchKernelGGL(conv1x1_wgrad_multi_kernel, dim3(nblk, N, ci_tiles * co_tiles), dim3(256), 0, st, dy, x, part, Cin, Cout,
+                               S, nblk, ci_tiles, coef, relu);
+        } else if (vec)
             hipLaunchKernelGGL(conv1x1_wgrad_vec_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);
         else
             hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nblk, N), dim3(256), 0, st, dy, x, part, Cin, Cout, S, nblk, coef, relu);

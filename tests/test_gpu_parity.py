@@ -623,7 +623,11 @@ def test_trilinear_align_corners(case):
     check(xg.grad, xr.grad, f"trilinear bwd {case}", tol=1e-5)
 
 
-@pytest.mark.parametrize("case", [(2, 64, 1, (6, 10, 12)), (1, 8, 3, (7, 9, 11)), (2, 5, 11, (4, 4, 8))])
+@pytest.mark.parametrize("case", [(2, 64, 1, (6, 10, 12)), (1, 8, 3, (7, 9, 11)), (2, 5, 11, (4, 4, 8)),
+                                  # several output channels on 16-byte rows: the multi-output backward-weights kernel (the 1x1x1
+                                  # reshape convs of DC3DATGeneric, models.py:488-494): one partial block / three with a ragged
+                                  # last one / one input channel / two tiles of input and of output channels with tails
+                                  (2, 64, 8, (8, 16, 16)), (1, 20, 8, (12, 40, 40)), (3, 1, 8, (8, 8, 8)), (2, 13, 9, (4, 40, 60))])
 def test_conv1x1_head(case):
     from dram_amd import functional as HF
     N, Ci, Co, sp = case
@@ -641,6 +645,32 @@ def test_conv1x1_head(case):
     check(xg.grad, xr.grad, "conv1x1 dx")
     check(wg.grad, wr.grad, "conv1x1 dw")
     check(bg.grad, br.grad, "conv1x1 db")
+
+
+def test_conv1x1_bwd_lazy_several_outputs():
+    """dram_conv3d_k1_bwd_lazy with more than one output channel (the multi-output backward-weights kernel with the input
+    normalised + rectified on load): equals the plain entry on the materialised input."""
+    from dram_amd import _lib
+    N, Ci, Co, S = 2, 12, 8, 24 * 40 * 12
+    st = torch.cuda.current_stream().cuda_stream
+    x = dev(torch.randn(N, Ci, S, generator=g(71)))
+    dy = dev(torch.randn(N, Co, S, generator=g(72)))
+    w = dev(torch.randn(Co, Ci, generator=g(73)))
+    coef = dev(torch.rand(N * Ci * 2, generator=g(74)) - 0.3)
+    c = coef.view(N, Ci, 2)
+    xa = torch.relu(x * c[:, :, 0:1] + c[:, :, 1:2]).contiguous()
+    ws = torch.empty(max(16, _lib.lib.dram_conv3d_k1_bwd_ws_bytes(N, Ci, Co, S)), dtype=torch.uint8, device=DEV)
+    out = {}
+    for name, args in (("lazy", ("dram_conv3d_k1_bwd_lazy", dy.data_ptr(), x.data_ptr(), coef.data_ptr(), 1)),
+                       ("plain", ("dram_conv3d_k1_bwd", dy.data_ptr(), xa.data_ptr()))):
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty(Co, device=DEV)
+        _lib.call(*args, w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), N, Ci, Co, S, st)
+        out[name] = (dx, dw, db)
+    ref_dw = torch.einsum("nos,ncs->oc", dy.double(), xa.double())
+    check(out["lazy"][1], ref_dw, "k1 lazy dw vs fp64")
+    check(out["plain"][1], ref_dw, "k1 plain dw vs fp64")
+    check(out["lazy"][2], dy.double().sum((0, 2)), "k1 lazy dbias")
+    assert torch.equal(out["lazy"][0], out["plain"][0])                       # dx does not look at x
 
 
 def test_masked_mean_pooling():
