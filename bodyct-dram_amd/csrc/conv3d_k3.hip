@@ -71,7 +71,23 @@ struct ConvArgs {
     // wave's 64 outputs of that channel -> stats[(row * nparts + part) * 3]; null: not wanted.
     float* stats;
     int nparts;
+    // division by co_tiles / nbx / nby / nbz as a multiply + shift (the persistent (z,y) kernel decodes three item cursors per
+    // item: 17 runtime integer divisions, each a v_rcp_iflag sequence with a VALU -> SALU round trip, ~2,000 cycles per item)
+    unsigned dv_m[4], dv_s[4];
 };
+
+// x / d for x < 2^31 by a host-prepared multiply + shift: s = ceil(log2 d), m = ceil(2^(31 + s) / d) < 2^32,
+// x / d = mulhi(x, m) >> (s - 1) (exact: the error x e / (d 2^(31 + s)) stays below 2^-s <= 1 / d); d == 1: m = 0.
+static inline void fast_div_prepare(unsigned d, unsigned& m, unsigned& sh) {
+    if (d <= 1) { m = 0; sh = 0; return; }
+    unsigned s_ = 0;
+    while ((1ull << s_) < d) ++s_;
+    m = (unsigned)((((unsigned long long)1 << (31 + s_)) + d - 1) / d);
+    sh = s_ - 1;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned m, unsigned sh) {
+    return m ? (__umulhi(x, m) >> sh) : x;
+}
 
 constexpr int KC = 4;  // input channels per LDS stage
 
@@ -1138,13 +1154,12 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
     const int C1 = a.src.C1;
 
     auto decode = [&](KArgs k, int item, int& n, int& x0, int& y0, int& z0, int& co0) {
-        int b = item;
-        const int cot = k->co_tiles, nbx = k->nbx, nby = k->nby, nbz = k->nbz;
-        co0 = (b % cot) * 64; b /= cot;
-        x0 = (b % nbx) * BX; b /= nbx;
-        y0 = (b % nby) * 4; b /= nby;
-        z0 = (b % nbz) * G::BZ;
-        n = b / nbz;
+        unsigned b = (unsigned)item, q;         // (multiply + shift divisions: ConvArgs::dv_m)
+        q = fast_div(b, k->dv_m[0], k->dv_s[0]); co0 = (int)(b - q * (unsigned)k->co_tiles) * 64; b = q;
+        q = fast_div(b, k->dv_m[1], k->dv_s[1]); x0 = (int)(b - q * (unsigned)k->nbx) * BX; b = q;
+        q = fast_div(b, k->dv_m[2], k->dv_s[2]); y0 = (int)(b - q * (unsigned)k->nby) * 4; b = q;
+        q = fast_div(b, k->dv_m[3], k->dv_s[3]); z0 = (int)(b - q * (unsigned)k->nbz) * G::BZ;
+        n = (int)q;
     };
     // The whole pipeline is instantiated twice, for the patch stagers (waves 0-3) and the column stagers (waves 4-7), behind
     // ONE wave-uniform branch: with the role tested inside the loop the prefetch registers become phi nodes over the two
@@ -1404,8 +1419,8 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
             float* const kstats = k->stats;
             if (kstats) {
                 __builtin_amdgcn_sched_barrier(0);
-                const int cot = k->co_tiles;
-                const int box = (item / cot) % (k->nbx * k->nby * k->nbz);
+                // the box's number inside its sample, from the decoded coordinates (no division)
+                const int box = (int)((((unsigned)z0 / G::BZ) * (unsigned)k->nby + ((unsigned)y0 >> 2)) * (unsigned)k->nbx + (unsigned)x0 / BX);
                 stats_epilogue<1>([&](int t, int i) { return yv[t][i]; }, ok0, ok1, lane, kstats, (int64_t)n * kCout,
                                   co0 + 32 * ct, kCout, k->nparts, box * 4 + 2 * ty + xh);
                 __builtin_amdgcn_sched_barrier(0);
@@ -2557,6 +2572,10 @@ static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
+    fast_div_prepare((unsigned)a.co_tiles, a.dv_m[0], a.dv_s[0]);
+    fast_div_prepare((unsigned)a.nbx, a.dv_m[1], a.dv_s[1]);
+    fast_div_prepare((unsigned)a.nby, a.dv_m[2], a.dv_s[2]);
+    fast_div_prepare((unsigned)a.nbz, a.dv_m[3], a.dv_s[3]);
     const int64_t cus = persistent_blocks();
     const unsigned grid = (unsigned)(total < cus ? total : cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a, (int)total);
