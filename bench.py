@@ -43,7 +43,7 @@ def wz_factor(kernel_name):
     """Executed / algorithmic MFMA FLOPs of a conv kernel: 2/3 for the Winograd F(2,3)-along-z kernels (36 of 54
     multiply-adds), 4/9 for the F(2x2,3x3)-over-(z,y) kernels (16 products per channel pair and x tap for 4 outputs
     instead of 36: 24 of 54)."""
-    if "_wzy_" in kernel_name:
+    if "_wzy" in kernel_name:             # conv3d_k3_fwd_wzy_kernel, conv3d_k3_fwd_wzy16_kernel, conv3d_k3_wgrad_wzy_kernel<..>
         return 4.0 / 9.0
     return 2.0 / 3.0 if "_wz_" in kernel_name else 1.0
 
