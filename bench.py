@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-kernel-timer", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-att", action="store_true", help="skip the side lines (reference-shape steps, inference step, "
                     "measured ceilings) reported beside the headline")
+    ap.add_argument("--no-overlap", action="store_true", help="reduce the gradient buckets after backward instead of inside it "
+                    "(A/B of the overlap; N > 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only to rehearse the multi-rank path with several ranks on one GPU)")
     return ap.parse_args()
@@ -332,7 +334,7 @@ def main():
     model.checkpoint_mode = args.checkpoint_mode
     model = model.to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    trainer = DataParallelTrainer(model, opt)
+    trainer = DataParallelTrainer(model, opt, overlap=not args.no_overlap)
     batch = synthetic_batch(args.chunks, args.size, 100 + rank, dev)   # resident in HBM before timing
     vox_per_rank = args.chunks * args.size ** 3
 
@@ -377,6 +379,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timer, HF.TIMER = HF.TIMER, None
+    trainer_overlap, n_buckets, overlapped = trainer.overlap, len(trainer.buckets), trainer.overlapped_buckets
     # ---- outside the timed region: what the timed steps computed (a wrong-but-fast step must not look like a result)
     loss_hist = [(float(r), float(sg)) for r, sg in losses]
     with torch.no_grad():
@@ -494,6 +497,8 @@ def main():
             "loss": {"reg": [l[0] for l in loss_hist], "seg": [l[1] for l in loss_hist],
                      "param_abs_sum_after": psum, "finite": finite},
             "dist": dist_info,
+            "allreduce": None if world == 1 else {"overlapped_with_backward": bool(trainer_overlap), "buckets": n_buckets,
+                                                  "buckets_started_inside_backward": overlapped},
             "ceilings_measured": ceilings,
             "reference_shape_step": ref_shape, "attention_model_step": att, "inference_step": infer,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_note": cpu_note, "kernels": kernels,

@@ -124,8 +124,9 @@ class DataParallelTrainer:
     Per-rank BatchNorm statistics (the reference's default "bn") need no exchange.  `p.grad` of every parameter is a view
     into its bucket after the step (no per-step torch.cat, no copy back)."""
 
-    def __init__(self, model, optimizer, loss_fn=None, loss_factors=(2.0, 1.0), bucket_mb=32):
+    def __init__(self, model, optimizer, loss_fn=None, loss_factors=(2.0, 1.0), bucket_mb=32, overlap=True):
         self.model, self.opt = model, optimizer
+        self.overlap = bool(overlap)               # False: every bucket is reduced after the last backward (A/B, diagnostics)
         self.loss_fn = loss_fn or DeviceIntRegRefineLoss()
         self.loss_factors = loss_factors           # LOSS_FACTORS[:2] of st_dram_ref.py:42
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -227,7 +228,7 @@ class DataParallelTrainer:
             reg, seg = self.loss_fn(dense, b, refined=None if refined is dense else refined)
             share = len(b) / n_glob
             loss = self.loss_factors[0] * reg + self.loss_factors[1] * seg * share
-            overlap = self.world > 1 and lo == starts[-1]
+            overlap = self.overlap and self.world > 1 and lo == starts[-1]
             if overlap:
                 self.model.grad_sink = self._grad_sink
             try:

@@ -186,3 +186,5 @@ def test_bench_two_ranks_over_gloo_as_a_child_process():
     assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 32 ** 3 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
     assert line["roofline"] is not None and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1.0
     assert line["cpu_baseline"] is None and "N = 1" in line["cpu_baseline_note"]
+    ar = line["allreduce"]
+    assert ar["overlapped_with_backward"] and ar["buckets_started_inside_backward"] == ar["buckets"] >= 1, ar
