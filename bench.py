@@ -426,6 +426,18 @@ def main():
                         "note": "achieved/frac = MFMA FLOPs actually issued (Winograd: F(2,3) along z executes 36, "
                                 "F(2x2,3x3) over (z,y) 24 of the direct form's 54 multiply-adds per channel pair and "
                                 "voxel) / fp32-MFMA peak; algorithmic_equiv_tflops = direct-conv FLOPs of SURVEY 8(d) / time"}
+            mf = os.path.join(ROOT, "profiles", "pmc_mfma.json")       # per-kernel matrix-core counters (scripts/pmc_mfma.py)
+            if os.path.exists(mf) and (args.size, args.chunks, args.micro) == (128, 64, PMC_MICRO):
+                try:
+                    t = json.load(open(mf)).get(dom)
+                    if t:
+                        roofline["pmc_mfma_util"] = t["mfma_util"]
+                        roofline["pmc_mfma_flops_per_launch"] = t["mfma_flops_per_launch"]
+                        roofline["pmc_note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 over "
+                                                "the same workload (profiles/): share of SIMD-cycles with the matrix pipe busy at the "
+                                                "clock the chip held, and the fp32 MFMA FLOPs it counted per launch")
+                except Exception:
+                    pass
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
             # (collected on the default workload, 64 x 128^3 as one batch: only that workload has the same launches)
             if os.path.exists(pmc) and (args.size, args.chunks, args.micro) == (128, 64, PMC_MICRO):
