@@ -72,21 +72,24 @@ struct ConvArgs {
     float* stats;
     int nparts;
     // division by co_tiles / nbx / nby / nbz as a multiply + shift (the persistent (z,y) kernel decodes three item cursors per
-    // item: 17 runtime integer divisions, each a v_rcp_iflag sequence with a VALU -> SALU round trip, ~2,000 cycles per item)
-    unsigned dv_m[4], dv_s[4];
+    // item: 17 runtime integer divisions, each a v_rcp_iflag sequence with a VALU -> SALU round trip, ~2,000 cycles per item).
+    // One 48-byte record {divisor, multiplier, shift} x 4, so that a decode reads it with three wide scalar loads.
+    alignas(16) unsigned dv_d[4];
+    alignas(16) unsigned dv_m[4];
+    alignas(16) unsigned dv_s[4];
 };
 
-// x / d for x < 2^31 by a host-prepared multiply + shift: s = ceil(log2 d), m = ceil(2^(31 + s) / d) < 2^32,
-// x / d = mulhi(x, m) >> (s - 1) (exact: the error x e / (d 2^(31 + s)) stays below 2^-s <= 1 / d); d == 1: m = 0.
+// x / d for x < 2^31 by a host-prepared multiply + shift (Granlund-Montgomery, branch-free): l = ceil(log2 d),
+// m = floor(2^32 (2^l - d) / d) + 1, x / d = (mulhi(x, m) + x) >> l (d == 1: l = 0, m = 1: mulhi = 0).
 static inline void fast_div_prepare(unsigned d, unsigned& m, unsigned& sh) {
-    if (d <= 1) { m = 0; sh = 0; return; }
-    unsigned s_ = 0;
-    while ((1ull << s_) < d) ++s_;
-    m = (unsigned)((((unsigned long long)1 << (31 + s_)) + d - 1) / d);
-    sh = s_ - 1;
+    if (d == 0) d = 1;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)(((((unsigned long long)1 << l) - d) << 32) / d + 1);
+    sh = l;
 }
 __device__ __forceinline__ unsigned fast_div(unsigned x, unsigned m, unsigned sh) {
-    return m ? (__umulhi(x, m) >> sh) : x;
+    return (__umulhi(x, m) + x) >> sh;
 }
 
 constexpr int KC = 4;  // input channels per LDS stage
@@ -1154,11 +1157,14 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
     const int C1 = a.src.C1;
 
     auto decode = [&](KArgs k, int item, int& n, int& x0, int& y0, int& z0, int& co0) {
-        unsigned b = (unsigned)item, q;         // (multiply + shift divisions: ConvArgs::dv_m)
-        q = fast_div(b, k->dv_m[0], k->dv_s[0]); co0 = (int)(b - q * (unsigned)k->co_tiles) * 64; b = q;
-        q = fast_div(b, k->dv_m[1], k->dv_s[1]); x0 = (int)(b - q * (unsigned)k->nbx) * BX; b = q;
-        q = fast_div(b, k->dv_m[2], k->dv_s[2]); y0 = (int)(b - q * (unsigned)k->nby) * 4; b = q;
-        q = fast_div(b, k->dv_m[3], k->dv_s[3]); z0 = (int)(b - q * (unsigned)k->nbz) * G::BZ;
+        // (multiply + shift divisions: ConvArgs::dv_*; the record is read as three 16-byte scalar loads, issued together)
+        typedef const __attribute__((address_space(4))) u32x4* K4;
+        const u32x4 dd = *(K4)&k->dv_d[0], dm = *(K4)&k->dv_m[0], ds = *(K4)&k->dv_s[0];
+        unsigned b = (unsigned)item, q;
+        q = fast_div(b, dm[0], ds[0]); co0 = (int)(b - q * dd[0]) * 64; b = q;
+        q = fast_div(b, dm[1], ds[1]); x0 = (int)(b - q * dd[1]) * BX; b = q;
+        q = fast_div(b, dm[2], ds[2]); y0 = (int)(b - q * dd[2]) * 4; b = q;
+        q = fast_div(b, dm[3], ds[3]); z0 = (int)(b - q * dd[3]) * G::BZ;
         n = (int)q;
     };
     // The whole pipeline is instantiated twice, for the patch stagers (waves 0-3) and the column stagers (waves 4-7), behind
@@ -1214,7 +1220,10 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
         };
 
         // ---- compute role: wave = (y pair ty, channel tile ct, xi_z half xh); lane = (x position j, channel parity kh) ----
-        const int ty = wave & 1, ct = (wave >> 1) & 1, xh = wave >> 2;
+        // (xh, the xi_z half, IS the staging role: waves 4 .. 7 -- a compile-time constant of this instantiation, so that the
+        //  epilogue's "which half am I" selects fold away: ~100 v_cndmask per item and wave as a runtime value)
+        const int ty = wave & 1, ct = (wave >> 1) & 1;
+        constexpr int xh = EXTRA ? 1 : 0;
         const int j = lane & 31, kh = lane >> 5;
         // column j of the wave's tile = x position j of y pair ty (BX = 32) / x position j % 16 of y pair j / 16 of z pair ty (BX = 16)
         const int bbase = kh * KHS + 8 * xh * XI + (BX == 32 ? G::pos(0, ty, j) : G::pos(ty, j >> 4, j & 15));
@@ -2572,10 +2581,8 @@ static int launch_fwd_wzy_f(ConvArgs& a, unsigned nblk, hipStream_t st) {
         set_error("conv3d_k3_fwd: grid too large");
         return DRAM_EINVAL;
     }
-    fast_div_prepare((unsigned)a.co_tiles, a.dv_m[0], a.dv_s[0]);
-    fast_div_prepare((unsigned)a.nbx, a.dv_m[1], a.dv_s[1]);
-    fast_div_prepare((unsigned)a.nby, a.dv_m[2], a.dv_s[2]);
-    fast_div_prepare((unsigned)a.nbz, a.dv_m[3], a.dv_s[3]);
+    a.dv_d[0] = (unsigned)a.co_tiles; a.dv_d[1] = (unsigned)a.nbx; a.dv_d[2] = (unsigned)a.nby; a.dv_d[3] = (unsigned)a.nbz;
+    for (int i = 0; i < 4; ++i) fast_div_prepare(a.dv_d[i], a.dv_m[i], a.dv_s[i]);
     const int64_t cus = persistent_blocks();
     const unsigned grid = (unsigned)(total < cus ? total : cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a, (int)total);
