@@ -24,10 +24,30 @@
 
 namespace dram {
 
-constexpr int CHUNK = 8192;  // floats per (row, chunk) work item: 256 threads x 8 float4
+#ifndef DRAM_NORM_Q
+#define DRAM_NORM_Q 4
+#endif
+constexpr int NQ = DRAM_NORM_Q;       // float4 per thread and tensor, all in flight together
+constexpr int CHUNK = 256 * 4 * NQ;   // floats per (row, chunk) work item: 256 threads x NQ float4
 
+// Streaming 16-byte accesses of the row kernels: non-temporal (every tensor here is far larger than the caches and is touched once
+// per pass), four per thread and tensor in flight.  Measured on [16,64,128^3] (scripts/bench_norm.py, same-box A/B of builds):
+// dram_norm_bwd 7.48 ms with default-policy accesses and eight per thread, 7.26 non-temporal, 7.11 non-temporal with four (7.22
+// with two); dram_row_affine_act 3.22 / 3.04 / 2.91 / 2.87 ms.  -DDRAM_NORM_TEMPORAL restores the default cache policy.
+#ifndef DRAM_NORM_TEMPORAL
+typedef float norm_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) {
+    const norm_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const norm_f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+    const norm_f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<norm_f32x4*>(p));
+}
+#else
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#endif
 
 // grid: (nchunks, rows).  part[(row*nchunks + chunk)*2] = {mean, M2} of that chunk.
 template <bool VEC>
@@ -46,14 +66,14 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
         // All 8 loads first, from clamped (always valid) addresses, and only then the arithmetic: a load inside
         // `if (e < len)` makes hipcc emit branch + load + s_waitcnt vmcnt(0) per slot, i.e. 8 serialised memory
         // latencies per thread (measured: 2.5 TB/s; 6.2 without the guards).  len % 4 == 0 on this path.
-        float4 t[8];
+        float4 t[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             t[q] = ld4(p + (e < len ? e : 0));
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             const bool in = e < len;
             v[4 * q] = in ? t[q].x : 0.f; v[4 * q + 1] = in ? t[q].y : 0.f;
@@ -73,7 +93,7 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
     float m2 = 0.f;
     if (VEC) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             if (e < len) {
 #pragma unroll
@@ -209,14 +229,14 @@ __global__ __launch_bounds__(256) void row_affine_act_kernel(const float* __rest
     const float* p = x + row * S + beg;
     float* o = y + row * S + beg;
     if (VEC) {
-        float4 tv[8];       // loads first, unconditional (see row_moments_kernel)
+        float4 tv[NQ];       // loads first, unconditional (see row_moments_kernel)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             tv[q] = ld4(p + (e < len ? e : 0));
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             float4 t = tv[q];
             t.x = fmaf(a, t.x, b); t.y = fmaf(a, t.y, b); t.z = fmaf(a, t.z, b); t.w = fmaf(a, t.w, b);
@@ -253,16 +273,16 @@ __global__ __launch_bounds__(256) void row_bwd_reduce_kernel(const float* __rest
     const float* pd = dy + row * S + beg;
     float s1 = 0.f, s2 = 0.f;
     if (VEC) {
-        float4 xq[8], dq[8];    // loads first, unconditional (see row_moments_kernel)
+        float4 xq[NQ], dq[NQ];    // loads first, unconditional (see row_moments_kernel)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             const int ec = e < len ? e : 0;
             xq[q] = ld4(px + ec);
             dq[q] = ld4(pd + ec);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             const bool in = e < len;
             const float xs[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
@@ -389,16 +409,16 @@ __global__ __launch_bounds__(256) void row_bwd_apply_kernel(const float* __restr
     const float* pd = dy + row * S + beg;
     float* o = dx + row * S + beg;
     if (VEC) {
-        float4 xq[8], dq[8];    // loads first, unconditional (see row_moments_kernel)
+        float4 xq[NQ], dq[NQ];    // loads first, unconditional (see row_moments_kernel)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             const int ec = e < len ? e : 0;
             xq[q] = ld4(px + ec);
             dq[q] = ld4(pd + ec);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = (q * 256 + threadIdx.x) * 4;
             const float xs[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
             float ds[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w};
