@@ -1538,7 +1538,7 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
     #endif
     #ifndef DRAM_WZY_DIAG_NOSTAGE
             if (it == SL0 - 1 && half == 1) read_raw(raw0 + (cur_ ^ 1) * G::RAW_STAGE);
-            if (it == SL0 && lazy) activate(half);
+            if (it == SL0 && lazy && lc_has) activate(half);       // (a plain channel of a launch with a lazy source: nothing to do)
             if (it == SL0 + 1 && half == 0) transform_z();
             const int q = 2 * (it - SL0 - 1) + half - 1;            // SL0+1: -, 0;  SL0+2: 1, 2;  SL0+3: 3, -
             if (q >= 0 && q < 4) transform_y_store(nstage + st_idx, q);
@@ -1627,6 +1627,7 @@ struct WgradArgs {
     float* slabs;     // [SPLIT][Cout][Cin][27]
     int N, Cin, Cout, D, H, W;
     int nbx, nby, nbz, nboxes, split, ci_tiles, co_tiles;
+    int ci_tile0;     // first 16-channel ci tile of this launch ((z,y) kernel: a launch may cover the tiles of ONE source only)
     // normalise + ReLU on load of x (see ConvArgs::coef1): source k holds the RAW conv output, the operand is
     // act(coefk[row][0] * x + coefk[row][1]); Winograd kernel only (the host materialises for the others)
     const float* coef1;
@@ -2479,11 +2480,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_c1_kernel(WgradC1Args 
 
 static inline int wgrad_c1_blocks(int nboxes) { return nboxes < 1024 ? nboxes : 1024; }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t E, int split) {
+// out[co][ci][tap] = sum over the first `split` slabs (input channels >= C1: over the first `split2` slabs -- backward-weights of a
+// virtual concat run as one launch per source, each with its own split; C1 = Cin: one split)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t E, int split, int Cin,
+                                   int C1, int split2) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
+    int n = split;
+    if (Cin > 0 && (int)((e / 27) % Cin) >= C1) n = split2;
     float s = 0.f;
-    for (int p = 0; p < split; ++p) s += slabs[(size_t)p * E + e];
+    for (int p = 0; p < n; ++p) s += slabs[(size_t)p * E + e];
     out[e] = s;
 }
 
@@ -2880,6 +2886,28 @@ static int conv_fwd_dispatch(ConvArgs& a, hipStream_t st) {
     }
 }
 
+// Split of the (z,y) backward-weights kernel's box range over blocks: one 512-thread block per CU; contiguous box ranges, so the
+// split only has to fill the device evenly (`tiles` = (ci tile, co tile) pairs of the launch, `slab` = bytes of one partial dW)
+static int wzy_split(int tiles, int nboxes, size_t slab, size_t ws_cap = (size_t)1 << 30) {
+    const int resident = 256;
+    int best = 1;
+    double best_score = -1.0;
+    for (int sp = 1; sp <= nboxes && sp <= 4096; ++sp) {
+        const int64_t blocks = (int64_t)tiles * sp;
+        if (blocks > 4LL * resident && sp > 1) break;
+        if ((size_t)sp * slab > ws_cap && sp > 1) break;
+        const int64_t rounds = (blocks + resident - 1) / resident;
+        double util = (double)blocks / (double)(rounds * resident);
+        const int64_t per = (nboxes + sp - 1) / sp;
+        util *= (double)nboxes / (double)(per * sp);
+        const double score = util + 1e-3 * (blocks >= 2LL * resident ? 1.0 : (double)blocks / (2.0 * resident));
+        if (score > best_score) { best_score = score; best = sp; }
+    }
+    return best;
+}
+
+constexpr size_t kWgradSubWsCap = (size_t)256 << 20;      // partial slabs of a per-source launch of a virtual concat
+
 struct WgradPlan {
     int variant;  // 0: block = 64 co x 32 ci (Cout <= 64);  1: block = 128 co x 16 ci
     int wz;       // 1: Winograd-z kernel (boxes = bx x by positions of a plane pair)
@@ -2910,24 +2938,7 @@ static WgradPlan wgrad_plan(int N, int Cin, int Cout, int D, int H, int W, int C
             p.nboxes = (int)((int64_t)N * p.nbx * p.nby * p.nbz);
             p.ci_tiles = cdiv(Cin, 16 * cit);
             p.co_tiles = cdiv(Cout, 64);
-            // one 256-thread block per CU; contiguous box ranges, so the split only has to fill the device evenly
-            const int tiles = p.ci_tiles * p.co_tiles;
-            const int resident = 256;
-            const size_t slab = (size_t)Cout * Cin * 27 * sizeof(float);
-            int best = 1;
-            double best_score = -1.0;
-            for (int sp = 1; sp <= p.nboxes && sp <= 4096; ++sp) {
-                const int64_t blocks = (int64_t)tiles * sp;
-                if (blocks > 4LL * resident && sp > 1) break;
-                if ((size_t)sp * slab > ((size_t)1 << 30) && sp > 1) break;
-                const int64_t rounds = (blocks + resident - 1) / resident;
-                double util = (double)blocks / (double)(rounds * resident);
-                const int64_t per = (p.nboxes + sp - 1) / sp;
-                util *= (double)p.nboxes / (double)(per * sp);
-                const double score = util + 1e-3 * (blocks >= 2LL * resident ? 1.0 : (double)blocks / (2.0 * resident));
-                if (score > best_score) { best_score = score; best = sp; }
-            }
-            p.split = best;
+            p.split = wzy_split(p.ci_tiles * p.co_tiles, p.nboxes, (size_t)Cout * Cin * 27 * sizeof(float));
             return p;
         }
     }
@@ -3263,9 +3274,16 @@ extern "C" size_t dram_conv3d_k3_wgrad_ws_bytes(int N, int Cin, int Cout, int D,
         const int64_t nboxes = (int64_t)N * cdiv(W, 32) * cdiv(H, 4) * cdiv(D, 2);
         return (size_t)4 * wgrad_c1_blocks((int)(nboxes < 0x7fffffff ? nboxes : 0x7fffffff)) * Cout * 27 * sizeof(float);
     }
-    // the split depends on whether a virtual-concat input lets the Winograd kernel run: size for the larger
+    // the split depends on whether a virtual-concat input lets the Winograd kernel run: size for the larger -- and, where the
+    // (z,y) kernel runs, for a per-source launch of a concat with one lazy source (fewer tiles, a finer split: wgrad_run)
     const WgradPlan p = wgrad_plan(N, Cin, Cout, D, H, W, 0), q = wgrad_plan(N, Cin, Cout, D, H, W, 1);
-    return (size_t)(p.split > q.split ? p.split : q.split) * Cout * Cin * 27 * sizeof(float);
+    const size_t slab = (size_t)Cout * Cin * 27 * sizeof(float);
+    int split = p.split > q.split ? p.split : q.split;
+    if (p.wzy && Cin > 16) {
+        const int sub = wzy_split(p.co_tiles, p.nboxes, slab, kWgradSubWsCap);
+        split = sub > split ? sub : split;
+    }
+    return (size_t)split * slab;
 }
 
 // 1 if backward-weights of this shape can take its x operand lazily (normalise + ReLU on load): the Winograd kernel
@@ -3316,7 +3334,7 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
         g_launches[DRAM_K3_WGRAD_C1].fetch_add(1, std::memory_order_relaxed);
         hipLaunchKernelGGL(conv3d_k3_wgrad_c1_kernel, dim3(blocks, cdiv(Cout, 32)), dim3(256), 0, st1, c);
         const int64_t E1 = (int64_t)Cout * 27;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E1, 256)), dim3(256), 0, st1, c.slabs, dw, E1, 4 * blocks);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E1, 256)), dim3(256), 0, st1, c.slabs, dw, E1, 4 * blocks, 0, 0, 0);
         return check_launch("conv3d_k3_wgrad(c1)");
     }
     // running 32-bit offsets walk up to 128 channel planes past the last one: they must not wrap
@@ -3337,6 +3355,28 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
     const WgradKernel wk = wgrad_kernel(p, C1, x2 != nullptr, W, a.coef1 || a.coef2);
     g_launches[wk.kind].fetch_add(1, std::memory_order_relaxed);
     const bool vec = wk.kind == DRAM_K3_WGRAD_VEC;
+    const int64_t E = (int64_t)Cout * a.Cin * 27;
+    if (p.wzy && x2 && (a.coef1 != nullptr) != (a.coef2 != nullptr) && getenv("DRAM_WGRAD_ONE_LAUNCH") == nullptr) {
+        // A virtual concat with exactly ONE lazy source (the first conv of an UpsampleConvBlock5d in the fused engine: the
+        // upsampled part plain, the skip part lazy): one launch per source, each on its own instantiation and with its own
+        // split.  In one launch the lazy tiles' blocks run ~9 % longer per box than the plain tiles', the blocks of a split
+        // drift apart and stop sharing dY in L2: measured [4,128+64->64,128^3] 23.3 ms as one launch (all-lazy 22.0, plain 20.7).
+        // The launches write disjoint input-channel columns of the same partial slabs; the reduce takes each column's split.
+        const int t1 = a.src.C1 / 16, t2 = cdiv(a.src.C2, 16);
+        const size_t cap = ws_bytes < kWgradSubWsCap ? ws_bytes : kWgradSubWsCap;   // (ws_bytes >= need: checked above)
+        const int s1 = wzy_split(t1 * p.co_tiles, p.nboxes, (size_t)E * sizeof(float), cap);
+        const int s2 = wzy_split(t2 * p.co_tiles, p.nboxes, (size_t)E * sizeof(float), cap);
+        WgradArgs b = a;
+        a.ci_tile0 = 0; a.ci_tiles = t1; a.split = s1; a.coef2 = nullptr;
+        b.ci_tile0 = t1; b.ci_tiles = t2; b.split = s2; b.coef1 = nullptr;
+        g_launches[wk.kind].fetch_add(1, std::memory_order_relaxed);
+        rc = launch_wgrad_wzy(a, st);
+        if (rc) return rc;
+        rc = launch_wgrad_wzy(b, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, a.slabs, dw, E, s1, a.Cin, a.src.C1, s2);
+        return check_launch("conv3d_k3_wgrad(reduce)");
+    }
     if (p.wzy) {
         rc = launch_wgrad_wzy(a, st);
     } else if (p.wz) {
@@ -3364,8 +3404,7 @@ static int wgrad_run(const float* x1, int C1, const float* coef1, int relu1, con
         else rc = launch_wgrad<8, 4, 2, 4, 2>(a, st);
     }
     if (rc) return rc;
-    const int64_t E = (int64_t)Cout * a.Cin * 27;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, a.slabs, dw, E, p.split);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, a.slabs, dw, E, p.split, 0, 0, 0);
     return check_launch("conv3d_k3_wgrad(reduce)");
 }
 

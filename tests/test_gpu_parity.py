@@ -358,6 +358,11 @@ WGRAD_WZY_CASES = [
     (2, 16, 16, 80, (4, 6, 40), (2, 3, 4), True, 0),      # W = 40 (the 40^3 level of an 80^3 chunk): ragged third box along x, lazy
     (1, 32, 0, 64, (6, 4, 72), (0, 0, 0), False, 0),      # W = 72: four full boxes + half a box, plain
     (1, 16, 0, 64, (4, 4, 28), (0, 0, 0), True, 0),       # W = 28: the second box holds 12 of its 16 columns
+    # exactly ONE lazy source (the first conv of an up-block in the fused engine: upsampled part plain, skip lazy): one launch
+    # per source, each with its own split, disjoint columns of the same slabs
+    (2, 32, 16, 64, (4, 6, 32), (2, 3, 4), "x2", 0),
+    (3, 16, 48, 80, (6, 4, 16), (0, 0, 0), "x2", 0),      # more lazy than plain tiles, two co tiles, same-size skip
+    (2, 32, 32, 64, (4, 4, 16), (2, 2, 4), "x1", 0),      # ... the other way round
 ]
 
 
@@ -387,9 +392,10 @@ def test_conv3d_k3_wgrad_wzy_fused(case):
     x2 = dev(torch.randn(N, C2, D + extra[0], H + extra[1], W + extra[2], generator=g(62))) if C2 else None
     crop = tuple(int(np.ceil(e / 2)) for e in extra) if C2 else (0, 0, 0)
     dy = place(torch.randn(N, Co, D, H, W, generator=g(63)), off)
-    coef1 = dev(torch.rand(N * C1 * 2, generator=g(64)) + 0.25) if lazy else None          # per (sample, channel): all different
-    coef2 = dev(torch.rand(N * C2 * 2, generator=g(65)) - 0.3) if (lazy and C2) else None
-    assert "wgrad_wzy" in HF.conv_wgrad_kernel_name(N, (D, H, W), Co, C1, C2, lazy=lazy)
+    coef1 = dev(torch.rand(N * C1 * 2, generator=g(64)) + 0.25) if lazy in (True, "x1") else None   # per (sample, channel): all different
+    coef2 = dev(torch.rand(N * C2 * 2, generator=g(65)) - 0.3) if (lazy in (True, "x2") and C2) else None
+    mixed = lazy in ("x1", "x2")
+    assert "wgrad_wzy" in HF.conv_wgrad_kernel_name(N, (D, H, W), Co, C1, C2, lazy=bool(lazy))
 
     def run(wzy):
         if wzy:
@@ -405,7 +411,7 @@ def test_conv3d_k3_wgrad_wzy_fused(case):
                       p(ws), ws.numel(), N, Co, D, H, W, st)
             torch.cuda.synchronize()
             delta = [a - b for a, b in zip(HF.conv_launch_counts(), before)]
-            assert delta[HF.K3_WGRAD_WZY] == (1 if wzy else 0) and sum(delta) == 1, (case, wzy, delta)
+            assert delta[HF.K3_WGRAD_WZY] == ((2 if mixed else 1) if wzy else 0) and sum(delta) == (2 if mixed and wzy else 1), (case, wzy, delta)
         finally:
             os.environ.pop("DRAM_WGRAD_NO_WZY", None)
         return dw
