@@ -12,9 +12,9 @@
 // All HBM-bound gathers/streams; one thread per output voxel.  The scan (int16) and the lobe label
 // map (uint8) stay resident in HBM; nothing goes back to the host except 5 boxes and 256 counts.
 //
-// Resampling grid: the reference resamples with SimpleITK (absent here: parity unpinned); this build
-// defines the crop -> R^3 resampling as trilinear with align_corners=True, the same operator the
-// reference itself uses for the way back (F.interpolate(..., align_corners=True), job_runner.py:767).
+// Resampling grid: the reference resamples the crop with SimpleITK (absent here: parity unpinned); the crop -> R^3 step
+// restates the grid of that ResampleImageFilter call from ITK's published semantics (itk_index below); the way back is the
+// reference's own F.interpolate(..., align_corners=True) (job_runner.py:767).
 #include "common.h"
 
 namespace dram {
@@ -88,6 +88,24 @@ __device__ __forceinline__ void ac_index(int in, int out, int o, int& i0, int& i
     l0 = 1.f - l1;
 }
 
+// The crop -> R^3 grid of the reference: Resample('fixed_size') (data_transforms.py:170-175) -> utils.resample ->
+// sitk.ResampleImageFilter.Execute(image, new_size, identity transform, sitkLinear, the image's own origin and direction,
+// new_spacing = spacing * size_in / size_out, fill 0) (utils.py:371-381).  SimpleITK is not available here (parity unpinned);
+// the grid is restated from ITK's published semantics of that call: output voxel o lies at physical position origin +
+// o * new_spacing, i.e. at continuous input index c = o * size_in / size_out; it is inside the input buffer while
+// c < size_in - 0.5 (ImageFunction::IsInsideBuffer: [-0.5, size - 0.5)), otherwise the default value 0; linear interpolation
+// between floor(c) and floor(c) + 1, the upper neighbour clamped to the last voxel (LinearInterpolateImageFunction).
+__device__ __forceinline__ void itk_index(int in, int out, int o, int& i0, int& i1, float& l0, float& l1, bool& inside) {
+    const double c = (double)o * (double)in / (double)out;
+    inside = c < (double)in - 0.5;
+    int b = (int)c;
+    b = b > in - 1 ? in - 1 : b;
+    i0 = b;
+    i1 = b + 1 <= in - 1 ? b + 1 : b;
+    l1 = i1 == i0 ? 0.f : (float)(c - (double)b);
+    l0 = 1.f - l1;
+}
+
 // out[l][R][R][R]: windowed, lobe-masked crop resampled to R^3
 __global__ __launch_bounds__(256) void lobe_chunks_kernel(const int16_t* __restrict__ scan,
                                                           const uint8_t* __restrict__ lobe, float* __restrict__ out,
@@ -99,9 +117,14 @@ __global__ __launch_bounds__(256) void lobe_chunks_kernel(const int16_t* __restr
     const int xo = e % R, yo = (e / R) % R, zo = e / (R * R);
     int z0, z1, y0, y1, x0, x1;
     float a0, a1, b0, b1, c0, c1;
-    ac_index(c.dz, R, zo, z0, z1, a0, a1);
-    ac_index(c.dy, R, yo, y0, y1, b0, b1);
-    ac_index(c.dx, R, xo, x0, x1, c0, c1);
+    bool inz, iny, inx;
+    itk_index(c.dz, R, zo, z0, z1, a0, a1, inz);
+    itk_index(c.dy, R, yo, y0, y1, b0, b1, iny);
+    itk_index(c.dx, R, xo, x0, x1, c0, c1, inx);
+    if (!(inz && iny && inx)) {                                   // beyond the crop's buffer (a crop smaller than R): default value
+        out[(size_t)l * R * R * R + e] = 0.f;
+        return;
+    }
     const float inv = 1.f / (wmax - wmin);
     auto at = [&](int z, int y, int x) -> float {
         const size_t o = ((size_t)(c.z0 + z) * H + (c.y0 + y)) * W + (c.x0 + x);

@@ -9,9 +9,11 @@ Otsu on the 8-bit heat map inside the lungs (`binary_cam`, dram/utils.py:226-242
 
 Differences from the reference, on purpose: the lobes (every non-zero label of the map, like
 `np.unique(lobe)[1:]`; normally 5) go through the model in batches of up to 8 chunks; the scan and the label map are uploaded once and every step runs on the device
-(the reference round-trips each lobe through numpy and SimpleITK); the crop -> 80^3 resampling is
-trilinear with align_corners=True (SimpleITK is not available here: that step's parity is unpinned;
-the way back uses the same operator as the reference's F.interpolate(align_corners=True)).
+(the reference round-trips each lobe through numpy and SimpleITK).  The crop -> 80^3 resampling restates the grid of the
+reference's call -- sitk.ResampleImageFilter with the identity transform, the crop's own origin and the output spacing
+spacing * size_in / size_out, linear, default value 0 (utils.py:371-381) -- from ITK's published semantics: output voxel o
+samples continuous input index o * size_in / size_out, zero beyond size_in - 0.5 (csrc/infer.hip:itk_index).  SimpleITK is not
+available here, so that step's parity is unpinned; the way back is the reference's own F.interpolate(align_corners=True).
 """
 import ctypes
 import math

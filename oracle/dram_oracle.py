@@ -463,11 +463,35 @@ def binary_cam(cam_np, scaler=1.0, from_span=(0, 1)):
     return w >= th, th / 255.0
 
 
+def resample_itk_linear(img, size):
+    """Resample('fixed_size') of a 3-D float image (data_transforms.py:170-175 -> utils.resample -> utils.py:371-381:
+    sitk.ResampleImageFilter.Execute(image, new_size, identity transform, sitkLinear, the image's origin and direction,
+    new_spacing = spacing * size_in / size_out, default value 0)).  SimpleITK 1.1.0 (requirements.in:33) is not installed
+    (PARITY UNPINNED); restated from ITK's published semantics of that call: output voxel o sits at continuous input index
+    c = o * size_in / size_out (same origin, identity transform); inside the buffer while c < size_in - 0.5
+    (ImageFunction::IsInsideBuffer), else the default value; linear interpolation between floor(c) and floor(c) + 1 with the
+    upper neighbour clamped to the last voxel (LinearInterpolateImageFunction).  fp64 here, fp32 on the device."""
+    out = np.asarray(img, dtype=np.float64)
+    inside = []
+    for ax, n_out in enumerate(size):
+        n_in = out.shape[ax]
+        c = np.arange(n_out, dtype=np.float64) * float(n_in) / float(n_out)
+        inside.append(c < n_in - 0.5)
+        b = np.minimum(c.astype(np.int64), n_in - 1)
+        u = np.minimum(b + 1, n_in - 1)
+        w1 = np.where(u == b, 0.0, c - b)
+        shape = [1, 1, 1]
+        shape[ax] = n_out
+        out = np.take(out, b, axis=ax) * (1.0 - w1).reshape(shape) + np.take(out, u, axis=ax) * w1.reshape(shape)
+    ok = inside[0][:, None, None] & inside[1][None, :, None] & inside[2][None, None, :]
+    return np.where(ok, out, 0.0).astype(np.float32)
+
+
 def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", resample=80,
                   window=(-1000.0, -300.0), border=5.0, forward=None):
     """evaluate_scan (job_runner.py:729-770) + the thresholding of LesionSegTest.run
     (job_runner.py:1003-1005), one lobe at a time like the reference.  The crop -> resample^3 step
-    uses trilinear/align_corners (this build's definition, see dram_amd/inference.py).
+    restates the grid of the reference's SimpleITK call from ITK's published semantics (resample_itk_linear: unpinned).
     `forward(t) -> logits` replaces the DC3D forward (e.g. the refined output of dc3dat_forward: the
     reference takes the model's *second* output, job_runner.py:764)."""
     htp = np.zeros(scan.shape, dtype=np.float32)
@@ -480,8 +504,7 @@ def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", r
             crop_size = lobe_chunk.shape
             scan_chunk[lobe_chunk == 0] = -2048
             img = windowing(scan_chunk, from_span=window, to_span=(0.0, 1.0)).astype(np.float32)
-            t = torch.from_numpy(img)[None, None]
-            t = upsample_trilinear_ac(t, size=(resample,) * 3)
+            t = torch.from_numpy(resample_itk_linear(img, (resample,) * 3))[None, None]
             dense = forward(t) if forward is not None else \
                 dc3d_forward(cfg, params, buffers, t, training=False, norm_method=norm_method)
             probs = torch.sigmoid(dense)

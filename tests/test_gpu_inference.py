@@ -122,9 +122,10 @@ def test_config5_full_size_whole_scan():
     """BASELINE config 5 at its stated size: a 300 x 512 x 512 synthetic CT with a 5-lobe label map through
     LobeInference (crop -> 80^3 -> model -> paste -> Otsu) on the device, against the oracle's evaluate_scan
     on the host (one lobe at a time, ~10 s).  Slim DC3D: the data path is what is at full size here; the
-    full-width model at 80^3 is covered by scripts/infer_bench.py.  NB the crop -> 80^3 resampling grid and
-    the Otsu restatement are this build's definitions on both sides (SimpleITK / skimage absent: that step's
-    parity with the reference is unpinned), so the Dice below is GPU path vs own CPU restatement."""
+    full-width model at 80^3 is covered by test_full_width_eval_inference_5_lobes_at_80.  NB the crop -> 80^3
+    resampling grid (restated from ITK's published semantics of the reference's ResampleImageFilter call) and the
+    Otsu restatement are unpinned on both sides (SimpleITK / skimage absent), so the Dice below is GPU path vs this
+    build's own CPU restatement."""
     import time
     from dram_amd.inference import LobeInference, dice, synthetic_ct
     scan, lobe, spacing = synthetic_ct((300, 512, 512), (1.0, 0.7, 0.7), seed=7, n_lesions=20)
@@ -259,3 +260,32 @@ def test_lesion_post_processing_tail(golden_dir):
     res2 = LobeInference(model, resample_size=32).run(scan, lobe, spacing, lesion=lesion)
     _, post2, _ = O.lesion_post_process(htp, scan, lobe, None, res["threshold"])
     assert np.array_equal(res2["mask_post"].cpu().numpy(), post2)
+
+
+def test_crop_resampling_grid_follows_the_itk_call():
+    """The crop -> R^3 step restates sitk.ResampleImageFilter(identity transform, same origin, spacing * in / out, linear, default 0)
+    (reference utils.py:371-381): output voxel o samples continuous index o * in / out; a crop SMALLER than R along an axis
+    leaves the output planes at c >= in - 0.5 at the default value 0 (IsInsideBuffer), the plane before them clamped to the last
+    voxel.  Device kernel against the oracle's fp64 restatement, and the two properties spelled out."""
+    from dram_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(11)
+    D, H, W, R = 10, 50, 33, 16                       # z: upsampled (10 -> 16), y: downsampled, x: 33 -> 16
+    scan = rng.integers(-1000, -300, size=(D, H, W)).astype(np.int16)
+    lobe = np.ones((D, H, W), dtype=np.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty((1, 1, R, R, R), device="cuda")
+    chunk = (ctypes.c_int * 7)(0, 0, 0, D, H, W, 1)
+    _lib.call("dram_lobe_chunks", torch.as_tensor(scan).cuda().data_ptr(), torch.as_tensor(lobe).cuda().data_ptr(), out.data_ptr(),
+              chunk, 1, D, H, W, R, -1000.0, -300.0, st)
+    got = out[0, 0].cpu().numpy()
+    img = O.windowing(scan.astype(np.float32), (-1000.0, -300.0)).astype(np.float32)
+    ref = O.resample_itk_linear(img, (R, R, R))
+    assert np.abs(got - ref).max() <= 1e-5
+    # z: c = o * 10 / 16: o = 15 -> 9.375 (clamped to the last plane, inside: < 9.5); nothing outside.  A 4-plane crop: o >= 14 -> 0
+    chunk4 = (ctypes.c_int * 7)(0, 0, 0, 4, H, W, 1)
+    _lib.call("dram_lobe_chunks", torch.as_tensor(scan).cuda().data_ptr(), torch.as_tensor(lobe).cuda().data_ptr(), out.data_ptr(),
+              chunk4, 1, D, H, W, R, -1000.0, -300.0, st)
+    got4 = out[0, 0].cpu().numpy()
+    assert (got4[14:] == 0).all() and (got4[13] != 0).any()            # c = 3.5 at o = 14: the first plane outside [-0.5, 3.5)
+    assert np.abs(got4 - O.resample_itk_linear(img[:4], (R, R, R))).max() <= 1e-5
