@@ -275,17 +275,16 @@ def test_crop_resampling_grid_follows_the_itk_call():
     lobe = np.ones((D, H, W), dtype=np.uint8)
     st = torch.cuda.current_stream().cuda_stream
     out = torch.empty((1, 1, R, R, R), device="cuda")
+    scan_d, lobe_d = torch.as_tensor(scan).cuda(), torch.as_tensor(lobe).cuda()      # (kept alive across the launches)
     chunk = (ctypes.c_int * 7)(0, 0, 0, D, H, W, 1)
-    _lib.call("dram_lobe_chunks", torch.as_tensor(scan).cuda().data_ptr(), torch.as_tensor(lobe).cuda().data_ptr(), out.data_ptr(),
-              chunk, 1, D, H, W, R, -1000.0, -300.0, st)
+    _lib.call("dram_lobe_chunks", scan_d.data_ptr(), lobe_d.data_ptr(), out.data_ptr(), chunk, 1, D, H, W, R, -1000.0, -300.0, st)
     got = out[0, 0].cpu().numpy()
     img = O.windowing(scan.astype(np.float32), (-1000.0, -300.0)).astype(np.float32)
     ref = O.resample_itk_linear(img, (R, R, R))
     assert np.abs(got - ref).max() <= 1e-5
     # z: c = o * 10 / 16: o = 15 -> 9.375 (clamped to the last plane, inside: < 9.5); nothing outside.  A 4-plane crop: o >= 14 -> 0
     chunk4 = (ctypes.c_int * 7)(0, 0, 0, 4, H, W, 1)
-    _lib.call("dram_lobe_chunks", torch.as_tensor(scan).cuda().data_ptr(), torch.as_tensor(lobe).cuda().data_ptr(), out.data_ptr(),
-              chunk4, 1, D, H, W, R, -1000.0, -300.0, st)
+    _lib.call("dram_lobe_chunks", scan_d.data_ptr(), lobe_d.data_ptr(), out.data_ptr(), chunk4, 1, D, H, W, R, -1000.0, -300.0, st)
     got4 = out[0, 0].cpu().numpy()
     assert (got4[14:] == 0).all() and (got4[13] != 0).any()            # c = 3.5 at o = 14: the first plane outside [-0.5, 3.5)
     assert np.abs(got4 - O.resample_itk_linear(img[:4], (R, R, R))).max() <= 1e-5
