@@ -431,6 +431,21 @@ def test_conv3d_k3_wgrad_wzy_fused(case):
     check(b, wr.grad, f"wgrad z-only {case}", tol=2e-5)
 
 
+@pytest.mark.parametrize("flags", [("--seed", "11"), ("--seed", "12", "--wzy")])
+def test_randomised_conv_sweep(flags):
+    """scripts/fuzz_conv.py: 40 random small shapes per run -- fused forward (lazy sources, cropped skip, statistics with the
+    total-count check), backward-data with a split destination (nothing written outside the crop window), fused
+    backward-weights (no / one / two lazy sources: the per-source launches) -- against an fp64 convolution, whichever kernel the
+    library picks; the second run biases the shapes towards the (z,y) kernels (16-wide boxes, ragged boxes).  390 such cases
+    were run once by hand (gpurun_out/fuzz*.log); this keeps 80 in the suite."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_conv.py"), "--cases", "40", *flags], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "cases agree" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_direct_conv_kernels_still_agree():
     """DRAM_CONV_DIRECT=1 routes every layer to the direct (27-tap) kernels that the Winograd ones replaced by default;
     they stay in the library as the A/B baseline and are kept verified by re-running the conv cases under that switch
