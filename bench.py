@@ -352,7 +352,12 @@ def main():
     for i in range(args.warmup):
         while True:
             try:
+                # The probe step reduces its gradients AFTER backward: an out-of-memory error in the middle of an overlapped
+                # backward would leave this rank with bucket all-reduces already issued that its retry issues again -- one
+                # collective more than its peers.  Without the overlap nothing is issued before the step is known to fit.
+                trainer.overlap = (not args.no_overlap) and i > 0
                 trainer.step(batch, micro)
+                trainer.overlap = not args.no_overlap
                 break
             except torch.OutOfMemoryError:
                 if micro <= 8:
@@ -362,6 +367,7 @@ def main():
                 micro //= 2
                 if rank == 0:
                     print(f"bench.py: out of memory, retrying with micro-batch {micro}", file=sys.stderr, flush=True)
+    trainer.overlap = not args.no_overlap
     if use_dist:       # every rank must run the same micro-batch (same number of launches between barriers)
         mt = torch.tensor([micro], device=dev)
         dist.all_reduce(mt, op=dist.ReduceOp.MIN)
