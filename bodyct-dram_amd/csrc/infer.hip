@@ -25,48 +25,60 @@ __global__ void bbox_init_kernel(int* boxes, int nlabels) {
     if (i < nlabels * 6) boxes[i] = (i % 6) < 3 ? 0x7fffffff : -1;
 }
 
+// One block per (plane z, band of BBOX_ROWS rows): the band is one contiguous span of the label map, read 16 voxels per thread
+// and step (rows of a multiple of 16 voxels on a 16-byte aligned map; one voxel per thread otherwise).  Every label 1..nlabels
+// is tracked (evaluate_scan visits every value of np.unique(lobe)[1:], job_runner.py:729, not just 1..5): per-label x / y
+// extents of the band in LDS -- an extent is only touched by an atomic when the voxel would widen it (a plain read first: the
+// extents are monotonic, a stale read costs at most a redundant atomic), so that the uniform interior of a lobe costs a read
+// per 16 voxels -- then one integer atomic set per label present in the band (deterministic).
+// (Round 3 ran one block per ROW: 153,600 blocks of 512 bytes for a 300 x 512 x 512 map, 2.7 ms; this form: see DESIGN.md.)
+constexpr int BBOX_ROWS = 64;
+__device__ __forceinline__ void bbox_note(int* lx0, int* lx1, int* ly0, int* ly1, int lab, int xa, int xb, int y) {
+    if (xa < lx0[lab]) atomicMin(&lx0[lab], xa);
+    if (xb > lx1[lab]) atomicMax(&lx1[lab], xb);
+    if (y < ly0[lab]) atomicMin(&ly0[lab], y);
+    if (y > ly1[lab]) atomicMax(&ly1[lab], y);
+}
 __global__ __launch_bounds__(256) void label_bboxes_kernel(const uint8_t* __restrict__ lobe, int* __restrict__ boxes,
                                                            int nlabels, int D, int H, int W) {
-    // One block per row (z, y), ONE pass over the row for every label 1..nlabels (evaluate_scan visits every
-    // value of np.unique(lobe)[1:], job_runner.py:729, not just 1..5): a wave peels the distinct labels among
-    // its 64 voxels (usually one or two), reduces their x extent with shuffles and merges it into the row's
-    // per-label extents in LDS; then one integer atomic set per label present in the row (deterministic).
-    __shared__ int lmin[256], lmax[256];
-    lmin[threadIdx.x] = 0x7fffffff;
-    lmax[threadIdx.x] = -1;
+    __shared__ int lx0[256], lx1[256], ly0[256], ly1[256];
+    lx0[threadIdx.x] = 0x7fffffff; lx1[threadIdx.x] = -1;
+    ly0[threadIdx.x] = 0x7fffffff; ly1[threadIdx.x] = -1;
     __syncthreads();
     const int z = blockIdx.y;
-    const int y = blockIdx.x;
-    const uint8_t* row = lobe + ((size_t)z * H + y) * W;
-    const int lane = threadIdx.x & 63;
-    for (int xb = 0; xb < W; xb += 256) {
-        const int x = xb + threadIdx.x;
-        const int v = x < W ? (int)row[x] : 0;
-        unsigned long long pending = __ballot(v != 0 && v <= nlabels);
-        while (pending) {
-            const int leader = __ffsll((long long)pending) - 1;
-            const int lab = __shfl(v, leader, 64);
-            const bool mine = v == lab;
-            int xmin = mine ? x : 0x7fffffff, xmax = mine ? x : -1;
+    const int y_lo = blockIdx.x * BBOX_ROWS;
+    const int nrows = (H - y_lo) < BBOX_ROWS ? (H - y_lo) : BBOX_ROWS;
+    const uint8_t* band = lobe + ((size_t)z * H + y_lo) * W;
+    const int n = nrows * W;
+    if ((W & 15) == 0 && (((size_t)band) & 15) == 0) {
+        for (int e = 16 * (int)threadIdx.x; e < n; e += 16 * 256) {
+            const uint4 v = *reinterpret_cast<const uint4*>(band + e);
+            const int y = y_lo + e / W, x = e % W;
+            const unsigned first = v.x & 0xffu;
+            const bool uniform = v.x == first * 0x01010101u && v.y == v.x && v.z == v.x && v.w == v.x;
+            if (uniform) {
+                if (first != 0 && (int)first <= nlabels) bbox_note(lx0, lx1, ly0, ly1, (int)first, x, x + 15, y);
+            } else {
+                const unsigned wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int a = __shfl_xor(xmin, o, 64), b = __shfl_xor(xmax, o, 64);
-                xmin = a < xmin ? a : xmin;
-                xmax = b > xmax ? b : xmax;
+                for (int k = 0; k < 16; ++k) {
+                    const int lab = (int)((wds[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                    if (lab != 0 && lab <= nlabels) bbox_note(lx0, lx1, ly0, ly1, lab, x + k, x + k, y);
+                }
             }
-            if (lane == leader) {
-                atomicMin(&lmin[lab], xmin);
-                atomicMax(&lmax[lab], xmax);
-            }
-            pending &= ~__ballot(mine);
+        }
+    } else {
+        for (int e = (int)threadIdx.x; e < n; e += 256) {
+            const int lab = (int)band[e];
+            if (lab != 0 && lab <= nlabels) bbox_note(lx0, lx1, ly0, ly1, lab, e % W, e % W, y_lo + e / W);
         }
     }
     __syncthreads();
     const int l = threadIdx.x;
-    if (l >= 1 && l <= nlabels && lmax[l] >= 0) {
+    if (l >= 1 && l <= nlabels && lx1[l] >= 0) {
         int* bx = boxes + (l - 1) * 6;
-        atomicMin(bx + 0, z); atomicMin(bx + 1, y); atomicMin(bx + 2, lmin[l]);
-        atomicMax(bx + 3, z); atomicMax(bx + 4, y); atomicMax(bx + 5, lmax[l]);
+        atomicMin(bx + 0, z); atomicMin(bx + 1, ly0[l]); atomicMin(bx + 2, lx0[l]);
+        atomicMax(bx + 3, z); atomicMax(bx + 4, ly1[l]); atomicMax(bx + 5, lx1[l]);
     }
 }
 
@@ -264,7 +276,7 @@ extern "C" int dram_label_bboxes(const uint8_t* lobe, int* boxes, int nlabels, i
     DRAM_REQUIRE(nlabels > 0 && nlabels <= 255 && D > 0 && H > 0 && W > 0 && D <= 65535, "label_bboxes: bad dimensions");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bbox_init_kernel, dim3(cdiv(nlabels * 6, 64)), dim3(64), 0, st, boxes, nlabels);
-    hipLaunchKernelGGL(label_bboxes_kernel, dim3(H, D), dim3(256), 0, st, lobe, boxes, nlabels, D, H, W);
+    hipLaunchKernelGGL(label_bboxes_kernel, dim3(cdiv(H, BBOX_ROWS), D), dim3(256), 0, st, lobe, boxes, nlabels, D, H, W);
     return check_launch("label_bboxes");
 }
 

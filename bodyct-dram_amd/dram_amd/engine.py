@@ -690,5 +690,6 @@ def run(model, x, taps=()):
         res = DC3DFusedFn.apply(model, taps, x, *params)
         dense, tapped = res[0], dict(zip(taps, res[1:]))
     else:
-        dense, tapped = forward(model, x, None, taps)
+        with HF.cached_packs():         # inference: unchanged filters are packed once, not per call
+            dense, tapped = forward(model, x, None, taps)
     return (dense, tapped) if taps else dense

@@ -446,6 +446,36 @@ def test_randomised_conv_sweep(flags):
     assert r.returncode == 0 and "cases agree" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_packed_filter_cache_follows_the_weights():
+    """Inference calls (functional.cached_packs(): the fused engine's no-gradient branch) reuse a filter's packed form while the
+    tensor is unchanged; an in-place update (optimiser step, load_state_dict) or a call outside the context must not see a
+    stale copy."""
+    from dram_amd import functional as HF
+    x = dev(torch.randn(1, 8, 4, 6, 16, generator=g(81)))
+    w = dev(torch.randn(16, 8, 3, 3, 3, generator=g(82)) * 0.1)
+    with torch.no_grad(), HF.cached_packs():
+        y0 = HF.conv3d_k3(x, w)
+        packed = HF._pack_cached(w)[0][2]
+        y1 = HF.conv3d_k3(x, w)
+        assert HF._pack_cached(w)[0][2] is packed and torch.equal(y0, y1)         # second call: no repack
+        w.mul_(2.0)                                                               # in-place update: version bump
+        y2 = HF.conv3d_k3(x, w)
+        assert HF._pack_cached(w)[0][2] is not packed
+    check(y2, 2.0 * y0, "conv after an in-place weight update", tol=1e-6)
+    wg = w.clone().requires_grad_(True)
+    HF.conv3d_k3(x, wg).sum().backward()                                          # a training call caches nothing
+    assert HF._pack_cached(wg) is None
+    HF.conv3d_k3(x, w.requires_grad_(True))                                       # ... and drops what evaluation left
+    assert HF._pack_cached(w) is None
+    n = len(HF._PACK_CACHE)
+    with torch.no_grad(), HF.cached_packs():
+        tmp = dev(torch.randn(16, 8, 3, 3, 3, generator=g(83)))
+        HF.conv3d_k3(x, tmp)
+        assert len(HF._PACK_CACHE) == n + 1
+        del tmp                                                                   # the entry dies with the tensor
+    assert len(HF._PACK_CACHE) == n
+
+
 def test_direct_conv_kernels_still_agree():
     """DRAM_CONV_DIRECT=1 routes every layer to the direct (27-tap) kernels that the Winograd ones replaced by default;
     they stay in the library as the A/B baseline and are kept verified by re-running the conv cases under that switch
