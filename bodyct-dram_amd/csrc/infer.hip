@@ -267,6 +267,69 @@ __global__ __launch_bounds__(256) void mask_overlap_kernel(const uint8_t* __rest
     if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
 }
 
+
+// ---- utils.resample(narray, spacing, required_spacing=..., new_size=..., interpolator=...) (utils.py:414-434 -> 299-381): the
+// volumes of LesionSegTest.run going back to the scan's original grid (job_runner.py:1016-1032).  sitk.ResampleImageFilter with
+// the identity transform, the image's own origin and direction, output spacing = required_spacing, default value 0, output
+// pixel type = input pixel type.  SimpleITK 1.1.0 is not available (PARITY UNPINNED); restated from ITK's published semantics:
+// output voxel o sits at continuous input index c = o * spacing_out / spacing_in per axis; it is inside the buffer while
+// c < size_in - 0.5 (ImageFunction::IsInsideBuffer; c >= 0 always: same origin), else the default value.
+//   nearest: voxel floor(c + 0.5) (NearestNeighborInterpolateImageFunction: Math::RoundHalfIntegerUp);
+//   linear:  base = floor(c), upper neighbour clamped to the last voxel, lerps x, then y, then z in double
+//            (LinearInterpolateImageFunction::EvaluateOptimized: RealType of short / float pixels is double), then the cast of
+//            ResampleImageFilter::CastPixelWithBoundsChecking: clamp to the pixel type's range, static_cast (int16: truncation).
+struct ResampleGrid {
+    int Di, Hi, Wi, Do, Ho, Wo;
+    double sz, sy, sx;          // spacing_out / spacing_in per axis
+};
+__device__ __forceinline__ double mul_rn(double a, double b) {       // (HIP's __dmul_rn is a plain `*`, open to contraction)
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ bool itk_axis(double c, int in, int& i0, int& i1, double& t) {
+#pragma clang fp contract(off)
+    const int b = (int)c;                                  // c >= 0
+    i0 = b > in - 1 ? in - 1 : b;
+    i1 = i0 + 1 <= in - 1 ? i0 + 1 : i0;
+    t = i1 == i0 ? 0.0 : c - (double)i0;
+    return c < (double)in - 0.5;
+}
+template <typename T> __device__ __forceinline__ T itk_cast(double v);
+template <> __device__ __forceinline__ float itk_cast<float>(double v) { return (float)v; }
+template <> __device__ __forceinline__ int16_t itk_cast<int16_t>(double v) {
+    return v < -32768.0 ? (int16_t)-32768 : v > 32767.0 ? (int16_t)32767 : (int16_t)v;
+}
+template <> __device__ __forceinline__ uint8_t itk_cast<uint8_t>(double v) {
+    return v < 0.0 ? (uint8_t)0 : v > 255.0 ? (uint8_t)255 : (uint8_t)v;
+}
+template <typename T, bool LINEAR>
+__global__ __launch_bounds__(256) void resample_volume_kernel(const T* __restrict__ in, T* __restrict__ out, ResampleGrid g) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= g.Wo) return;
+    const size_t o = ((size_t)z * g.Ho + y) * g.Wo + x;
+    // (products rounded on their own: hipcc would otherwise contract c - base into fma(o, s, -base), which is not what ITK or the oracle compute)
+    const double cz = mul_rn((double)z, g.sz), cy = mul_rn((double)y, g.sy), cx = mul_rn((double)x, g.sx);
+    int z0, z1, y0, y1, x0, x1;
+    double tz, ty, tx;
+    const bool inz = itk_axis(cz, g.Di, z0, z1, tz), iny = itk_axis(cy, g.Hi, y0, y1, ty), inx = itk_axis(cx, g.Wi, x0, x1, tx);
+    if (!(inz && iny && inx)) { out[o] = (T)0; return; }
+    auto at = [&](int zz, int yy, int xx) { return in[((size_t)zz * g.Hi + yy) * g.Wi + xx]; };
+    if (!LINEAR) {
+        out[o] = at((int)(cz + 0.5), (int)(cy + 0.5), (int)(cx + 0.5));       // (inside: c + 0.5 < size_in)
+        return;
+    }
+    // (no fused multiply-add: ITK's x86 builds round the product, and so does the oracle -- it shows where an int16 result
+    //  truncates: -484 + 705 * 0.4 is -202 with a rounded product, -201.99999999999997 fused.  HIP's __dmul_rn is a plain `*`.)
+    auto lerp = [](double a, double b, double t) {
+#pragma clang fp contract(off)
+        const double p = (b - a) * t;
+        return a + p;
+    };
+    const double v00 = lerp((double)at(z0, y0, x0), (double)at(z0, y0, x1), tx), v10 = lerp((double)at(z0, y1, x0), (double)at(z0, y1, x1), tx);
+    const double v01 = lerp((double)at(z1, y0, x0), (double)at(z1, y0, x1), tx), v11 = lerp((double)at(z1, y1, x0), (double)at(z1, y1, x1), tx);
+    out[o] = itk_cast<T>(lerp(lerp(v00, v10, ty), lerp(v01, v11, ty), tz));
+}
+
 }  // namespace dram
 
 using namespace dram;
@@ -372,4 +435,24 @@ extern "C" int dram_mask_overlap(const uint8_t* a, const uint8_t* b, unsigned lo
     const unsigned grid = (unsigned)(cdiv64(n, 256 * 16) < 2048 ? cdiv64(n, 256 * 16) : 2048);
     hipLaunchKernelGGL(mask_overlap_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, a, b, counts, (size_t)n);
     return check_launch("mask_overlap");
+}
+
+// kind: 0 = uint8, 1 = int16, 2 = float32 volumes; linear: 0 = nearest neighbour, 1 = linear.  spacing_*: (z, y, x).
+extern "C" int dram_resample_volume(const void* in, void* out, int kind, int linear, int Di, int Hi, int Wi, int Do, int Ho,
+                                    int Wo, const double* spacing_in, const double* spacing_out, void* stream) {
+    DRAM_REQUIRE(in && out && spacing_in && spacing_out, "resample_volume: null pointer");
+    DRAM_REQUIRE(kind >= 0 && kind <= 2 && (linear == 0 || linear == 1), "resample_volume: kind in 0..2, linear in 0..1");
+    DRAM_REQUIRE(Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0 && Ho <= 65535 && Do <= 65535,
+                 "resample_volume: bad dimensions");
+    ResampleGrid g{Di, Hi, Wi, Do, Ho, Wo, 0.0, 0.0, 0.0};
+    for (int a = 0; a < 3; ++a) DRAM_REQUIRE(spacing_in[a] > 0.0 && spacing_out[a] > 0.0, "resample_volume: spacings must be positive");
+    g.sz = spacing_out[0] / spacing_in[0]; g.sy = spacing_out[1] / spacing_in[1]; g.sx = spacing_out[2] / spacing_in[2];
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cdiv(Wo, 256), Ho, Do), block(256);
+#define DRAM_RS(T_, L_) hipLaunchKernelGGL((resample_volume_kernel<T_, L_>), grid, block, 0, st, (const T_*)in, (T_*)out, g)
+    if (kind == 0) { if (linear) DRAM_RS(uint8_t, true); else DRAM_RS(uint8_t, false); }
+    else if (kind == 1) { if (linear) DRAM_RS(int16_t, true); else DRAM_RS(int16_t, false); }
+    else { if (linear) DRAM_RS(float, true); else DRAM_RS(float, false); }
+#undef DRAM_RS
+    return check_launch("resample_volume");
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
     "dram_scan_hist256": (I, [P, P, P, I, I, L, P]),
     "dram_lesion_post": (I, [P, P, P, P, P, F, I, I, ctypes.c_double, L, P]),
     "dram_mask_overlap": (I, [P, P, P, L, P]),
+    "dram_resample_volume": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "dram_intreg_loss_ws_bytes": (Z, [I, L]),
     "dram_intreg_loss_state_floats": (I, [I]),
     "dram_intreg_loss_fwd": (I, [P, P, P, P, P, P, P, F, P, P, P, Z, I, L, P]),

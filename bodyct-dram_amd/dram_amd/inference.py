@@ -57,6 +57,28 @@ def binary_cam_threshold(hist, scaler=1.0):
     return min(otsu_threshold_from_hist(hist) * scaler, 255.0) / 255.0
 
 
+_RESAMPLE_KINDS = {torch.uint8: 0, torch.int16: 1, torch.float32: 2}
+
+
+def resample_volume(vol, spacing, required_spacing, new_size, interpolator="linear"):
+    """`utils.resample(narray, spacing, required_spacing=..., new_size=..., interpolator=...)` (dram/utils.py:414-434) of a
+    device volume [D,H,W] (uint8 / int16 / float32; the pixel type is kept like sitk's `orig_pixelid`): the grid of
+    sitk.ResampleImageFilter restated from ITK's published semantics (csrc/infer.hip: resample_volume_kernel; SimpleITK is not
+    available, parity unpinned).  spacing / required_spacing / new_size in (z, y, x) order like the reference's numpy side."""
+    if interpolator not in ("nearest", "linear"):
+        raise NotImplementedError(f"interpolator {interpolator!r}: the reference's inference uses 'nearest' and 'linear'")
+    if vol.dim() != 3 or vol.dtype not in _RESAMPLE_KINDS or not vol.is_cuda:
+        raise ValueError("resample_volume: a [D,H,W] uint8 / int16 / float32 tensor on the GPU")
+    vol = vol.contiguous()
+    size = [int(v) for v in new_size]
+    out = torch.empty(size, dtype=vol.dtype, device=vol.device)
+    sp_in = (ctypes.c_double * 3)(*[float(v) for v in spacing])
+    sp_out = (ctypes.c_double * 3)(*[float(v) for v in required_spacing])
+    call("dram_resample_volume", vol.data_ptr(), out.data_ptr(), _RESAMPLE_KINDS[vol.dtype], int(interpolator == "linear"),
+         *vol.shape, *size, sp_in, sp_out, torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 class LobeInference:
     """model: a models.DC3D on the GPU.  run(scan_i16, lobe_u8, spacing) -> dict.  Every label 1..max_labels
     present in the uint8 lobe map is visited in ascending order (evaluate_scan: `np.unique(lobe)[1:]`,
@@ -74,12 +96,14 @@ class LobeInference:
         self.post_window, self.post_scaler = (int(post_window[0]), int(post_window[1])), float(post_scaler)
 
     @torch.no_grad()
-    def run(self, scan, lobe, spacing, vessel=None, lesion=None):
+    def run(self, scan, lobe, spacing, vessel=None, lesion=None, original_spacing=None, original_size=None):
         """`vessel` (uint8 [D,H,W], optional): the vessel mask of LesionSegTest.run; with it (or with `lesion`) the result also
         holds the post-processed mask `mask_post` = mask & (windowed scan > brightness threshold) & ~vessel (job_runner.py:1006-1010).
         `lesion` (uint8 [D,H,W], optional): the reference mask; adds iou / iou_post / dice / dice_post (job_runner.py:1033-1037),
-        computed at the working resolution (the reference first resamples every mask to the original spacing with SimpleITK
-        nearest-neighbour, job_runner.py:1016-1032 -- absent here, the identity when the spacings agree)."""
+        computed at the working resolution unless `original_spacing` and `original_size` ((z, y, x), the scan's metadata) are
+        given: then, like job_runner.py:1016-1032, the masks (nearest neighbour), the scan and the heat map (linear) first go
+        back to the original grid (`resample_volume`; result key "original": mask / mask_post / lesion / scan / htp there) and
+        the four metrics are those of the resampled masks."""
         dev = next(self.model.parameters()).device
         scan = torch.as_tensor(scan).to(device=dev, dtype=torch.int16).contiguous()
         lobe = torch.as_tensor(lobe).to(device=dev, dtype=torch.uint8).contiguous()
@@ -136,15 +160,20 @@ class LobeInference:
         ratio = float(ssum.item()) / max(n_lung, 1)                          # (htp * (lobe>0)).sum() / (lobe>0).sum()
         res = {"htp": htp, "mask": mask, "threshold": th, "lesion_ratio": ratio, "ctss": ratio_to_label(ratio),
                "chunks": chunks, "input": x}
-        if vessel is not None or lesion is not None:
-            res.update(self.post_process(scan, lobe, htp, th, vessel, lesion, mask))
+        if vessel is not None or lesion is not None or original_size is not None:
+            res.update(self.post_process(scan, lobe, htp, th, vessel, lesion, mask, spacing=spacing,
+                                         original_spacing=original_spacing, original_size=original_size))
         return res
 
     @torch.no_grad()
-    def post_process(self, scan, lobe, htp, th, vessel=None, lesion=None, mask=None):
-        """The tail of LesionSegTest.run (job_runner.py:1006-1012, 1033-1037) on the device: brightness gate
+    def post_process(self, scan, lobe, htp, th, vessel=None, lesion=None, mask=None, spacing=None, original_spacing=None,
+                     original_size=None):
+        """The tail of LesionSegTest.run (job_runner.py:1006-1037) on the device: brightness gate
         `binary_cam(w_scan[lobe > 0], 0.75)` on the scan windowed with windowing()'s default span, lesion_pred_post =
-        lesion_pred & (w_scan > th) & ~(vessel > 0), and IOU / Dice against the reference lesion mask (utils.py:437-446)."""
+        lesion_pred & (w_scan > th) & ~(vessel > 0), the resampling to the scan's original grid when `original_spacing` /
+        `original_size` are given (job_runner.py:1016-1032), and IOU / Dice against the reference lesion mask (utils.py:437-446)."""
+        if (original_spacing is None) != (original_size is None) or (original_size is not None and spacing is None):
+            raise ValueError("post_process: spacing, original_spacing and original_size go together")
         dev = htp.device
         st = torch.cuda.current_stream().cuda_stream
         n = htp.numel()
@@ -158,13 +187,22 @@ class LobeInference:
         call("dram_lesion_post", htp.data_ptr(), scan.data_ptr(), None if vessel is None else vessel.data_ptr(), None,
              post.data_ptr(), float(th), self.post_window[0], self.post_window[1], float(th_scan), n, st)
         out = {"mask_post": post, "threshold_scan": th_scan}
+        if mask is None and (lesion is not None or original_size is not None):
+            mask = torch.empty(htp.shape, dtype=torch.uint8, device=dev)
+            call("dram_threshold_mask", htp.data_ptr(), mask.data_ptr(), float(th), n, st)
         if lesion is not None:
             lesion = torch.as_tensor(lesion).to(device=dev, dtype=torch.uint8).contiguous()
             if lesion.shape != htp.shape:
                 raise ValueError("lesion mask and scan must have the same shape")
-            if mask is None:
-                mask = torch.empty(htp.shape, dtype=torch.uint8, device=dev)
-                call("dram_threshold_mask", htp.data_ptr(), mask.data_ptr(), float(th), n, st)
+        if original_size is not None:
+            back = lambda v, how: resample_volume(v, spacing, original_spacing, original_size, how)
+            orig = {"mask": back(mask, "nearest"), "mask_post": back(post, "nearest"), "scan": back(scan, "linear"),
+                    "htp": back(htp, "linear")}
+            if lesion is not None:
+                orig["lesion"] = lesion = back(lesion, "nearest")
+            out["original"] = orig
+            mask, post, n = orig["mask"], orig["mask_post"], orig["mask"].numel()
+        if lesion is not None:
             counts = torch.empty(8, dtype=torch.int64, device=dev)
             call("dram_mask_overlap", mask.data_ptr(), lesion.data_ptr(), counts.data_ptr(), n, st)
             call("dram_mask_overlap", post.data_ptr(), lesion.data_ptr(), counts[4:].data_ptr(), n, st)

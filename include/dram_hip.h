@@ -238,6 +238,17 @@ int dram_lesion_post(const float* htp, const int16_t* scan, const uint8_t* vesse
                      int wmin, int wmax, double th_scan, int64_t n, void* stream);
 int dram_mask_overlap(const uint8_t* a, const uint8_t* b, unsigned long long* counts, int64_t n, void* stream);
 
+/* ---- utils.resample(narray, spacing, required_spacing=, new_size=, interpolator=) (dram/utils.py:414-434 -> 299-381), the way
+ *      LesionSegTest.run takes its masks (nearest), the scan and the heat map (linear) back to the scan's original grid
+ *      (dram/job_runner.py:1016-1032): sitk.ResampleImageFilter, identity transform, same origin / direction, default value 0,
+ *      output pixel type = input pixel type.  Restated from ITK's published semantics (SimpleITK absent: parity unpinned) --
+ *      output voxel o samples continuous index o * spacing_out / spacing_in; zero beyond size_in - 0.5; nearest = round half up;
+ *      linear in double with the upper neighbour clamped, integer pixels by clamp + truncation.
+ *      kind: 0 uint8, 1 int16, 2 float32; linear: 0 / 1; in: [Di][Hi][Wi], out: [Do][Ho][Wo]; spacing_*: 3 doubles (z, y, x),
+ *      HOST pointers. ---- */
+int dram_resample_volume(const void* in, void* out, int kind, int linear, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                         const double* spacing_in, const double* spacing_out, void* stream);
+
 /* ---- nn.PReLU (act_wrapper "prelu", dram/parts.py:51-52): y = x > 0 ? x : a*x, a[nparam], nparam in {1, C};
  *      x: [N,C,S].  bwd: dx (may be NULL), da[nparam] = sum dy*x over x <= 0 (deterministic) ---- */
 int dram_prelu_fwd(const float* x, const float* a, float* y, int N, int C, int nparam, int64_t S, void* stream);

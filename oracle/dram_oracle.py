@@ -487,6 +487,47 @@ def resample_itk_linear(img, size):
     return np.where(ok, out, 0.0).astype(np.float32)
 
 
+def resample_itk(narray, spacing, required_spacing, new_size, interpolator="linear"):
+    """utils.resample(narray, spacing, factor=2, required_spacing=..., new_size=..., interpolator=...) (utils.py:414-434 ->
+    resample_sitk_image, utils.py:299-381) as LesionSegTest.run calls it for the way back to the scan's original grid
+    (job_runner.py:1016-1032): sitk.ResampleImageFilter.Execute(image, new_size, identity transform, nearest / linear, the
+    image's origin and direction, required_spacing, default value 0, the image's own pixel type).  SimpleITK 1.1.0 is not
+    installed (PARITY UNPINNED); restated from ITK's published semantics: output voxel o sits at continuous input index
+    c = o * required_spacing / spacing per axis, inside the buffer while c < size_in - 0.5; nearest neighbour = floor(c + 0.5)
+    (Math::RoundHalfIntegerUp); linear = lerps along x, then y, then z in double with the upper neighbour clamped to the last
+    voxel; integer pixel types by clamp + truncation (ResampleImageFilter::CastPixelWithBoundsChecking).  Axes in (z, y, x)
+    order on both sides, as the reference's numpy side has them."""
+    a = np.asarray(narray)
+    idx, inside, frac = [], [], []
+    for ax in range(3):
+        n_in = a.shape[ax]
+        c = np.arange(int(new_size[ax]), dtype=np.float64) * (float(required_spacing[ax]) / float(spacing[ax]))
+        inside.append(c < n_in - 0.5)
+        if interpolator == "nearest":
+            idx.append((np.minimum((c + 0.5).astype(np.int64), n_in - 1),))
+        else:
+            b = np.minimum(c.astype(np.int64), n_in - 1)
+            u = np.minimum(b + 1, n_in - 1)
+            idx.append((b, u))
+            frac.append(np.where(u == b, 0.0, c - b))
+    ok = inside[0][:, None, None] & inside[1][None, :, None] & inside[2][None, None, :]
+    if interpolator == "nearest":
+        out = a[np.ix_(idx[0][0], idx[1][0], idx[2][0])]
+        return np.where(ok, out, 0).astype(a.dtype)
+    assert interpolator == "linear"
+    f = a.astype(np.float64)
+    tz, ty, tx = frac[0][:, None, None], frac[1][None, :, None], frac[2][None, None, :]
+    g = lambda i, j, k: f[np.ix_(idx[0][i], idx[1][j], idx[2][k])]
+    lerp = lambda p, q, t: p + (q - p) * t
+    v = lerp(lerp(lerp(g(0, 0, 0), g(0, 0, 1), tx), lerp(g(0, 1, 0), g(0, 1, 1), tx), ty),
+             lerp(lerp(g(1, 0, 0), g(1, 0, 1), tx), lerp(g(1, 1, 0), g(1, 1, 1), tx), ty), tz)
+    v = np.where(ok, v, 0.0)
+    if np.issubdtype(a.dtype, np.integer):
+        info = np.iinfo(a.dtype)
+        return np.trunc(np.clip(v, info.min, info.max)).astype(a.dtype)
+    return v.astype(a.dtype)
+
+
 def evaluate_scan(cfg, params, buffers, scan, lobe, spacing, norm_method="bn", resample=80,
                   window=(-1000.0, -300.0), border=5.0, forward=None):
     """evaluate_scan (job_runner.py:729-770) + the thresholding of LesionSegTest.run

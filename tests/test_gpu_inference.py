@@ -288,3 +288,72 @@ def test_crop_resampling_grid_follows_the_itk_call():
     got4 = out[0, 0].cpu().numpy()
     assert (got4[14:] == 0).all() and (got4[13] != 0).any()            # c = 3.5 at o = 14: the first plane outside [-0.5, 3.5)
     assert np.abs(got4 - O.resample_itk_linear(img[:4], (R, R, R))).max() <= 1e-5
+
+
+@pytest.mark.parametrize("case", ["up", "down", "mixed"])
+def test_resample_back_to_the_original_grid(case):
+    """`utils.resample(..., required_spacing=original_spacing, new_size=original_size)` of LesionSegTest.run (job_runner.py:1016-1032)
+    on the device (csrc/infer.hip dram_resample_volume) against the oracle's numpy restatement of the same sitk call: masks
+    (uint8, nearest) and the int16 scan (linear, clamp + truncation) BIT-exact -- the index arithmetic is the same fp64
+    expression on both sides --, the float heat map to 1e-6.  Parity against SimpleITK itself is unpinned (library absent)."""
+    from dram_amd.inference import resample_volume
+    rng = np.random.default_rng(5)
+    shape = (21, 34, 40)
+    spacing = (1.25, 0.8, 0.8)
+    if case == "up":                 # finer original grid; more voxels than the resampled extent covers along z (default value 0)
+        req, size = (0.5, 0.4, 0.4), (56, 68, 80)
+    elif case == "down":
+        req, size = (2.5, 1.5, 1.7), (10, 19, 18)
+    else:                            # same spacing along x (the identity there), coarser z, finer y, size cut short along y
+        req, size = (2.0, 0.3, 0.8), (11, 70, 40)
+    mask = (rng.random(shape) > 0.6).astype(np.uint8) * rng.integers(1, 6, size=shape).astype(np.uint8)
+    scan = rng.integers(-1200, 600, size=shape).astype(np.int16)
+    htp = rng.random(shape).astype(np.float32)
+    for arr, how, tol in ((mask, "nearest", 0), (scan, "linear", 0), (scan, "nearest", 0), (htp, "linear", 1e-6), (htp, "nearest", 0),
+                          (mask, "linear", 0)):
+        got = resample_volume(torch.as_tensor(arr).cuda(), spacing, req, size, how).cpu().numpy()
+        ref = O.resample_itk(arr, spacing, req, size, how)
+        assert got.shape == tuple(size) and got.dtype == arr.dtype
+        if tol == 0:
+            assert np.array_equal(got, ref), (case, arr.dtype, how, int((got != ref).sum()))
+        else:
+            assert np.abs(got - ref).max() <= tol
+    if case == "up":                 # c = o * 0.4: inside while c < 20.5 -> planes 52.. are the default value
+        got = resample_volume(torch.as_tensor(scan).cuda(), spacing, req, size, "linear").cpu().numpy()
+        assert (got[52:] == 0).all() and (got[51] != 0).any()
+    if case == "mixed":              # x: same spacing, same size: every x column is an input column
+        got = resample_volume(torch.as_tensor(htp).cuda(), (1.0, 1.0, 0.8), (1.0, 1.0, 0.8), shape, "linear")
+        assert torch.equal(got.cpu(), torch.as_tensor(htp))
+    with pytest.raises(NotImplementedError):
+        resample_volume(torch.as_tensor(htp).cuda(), spacing, req, size, "bspline")
+
+
+def test_lesion_metrics_on_the_original_grid():
+    """LobeInference.run(..., original_spacing=, original_size=): the masks / scan / heat map taken back to the scan's original
+    grid and IOU / Dice computed THERE (job_runner.py:1016-1037), against the oracle's restatement fed with the device heat map."""
+    from dram_amd.inference import LobeInference, synthetic_ct
+    scan, lobe, spacing = synthetic_ct((48, 80, 80), (1.4, 0.9, 0.9), seed=9, n_lesions=6)
+    rng = np.random.default_rng(4)
+    vessel = ((rng.random(scan.shape) > 0.92) & (lobe > 0)).astype(np.uint8)
+    lesion = ((scan > -600) & (lobe > 0)).astype(np.uint8)
+    o_spacing, o_size = (0.7, 0.6, 0.6), (96, 120, 120)
+    model = _model().cuda().eval()
+    res = LobeInference(model, resample_size=32).run(scan, lobe, spacing, vessel=vessel, lesion=lesion,
+                                                     original_spacing=o_spacing, original_size=o_size)
+    htp = res["htp"].cpu().numpy()
+    pred, post, _ = O.lesion_post_process(htp, scan, lobe, vessel, res["threshold"])
+    back = lambda a, how: O.resample_itk(a, spacing, o_spacing, o_size, how)
+    ref = {"mask": back(pred, "nearest"), "mask_post": back(post, "nearest"), "lesion": back(lesion, "nearest"),
+           "scan": back(scan, "linear"), "htp": back(htp, "linear")}
+    got = {k: v.cpu().numpy() for k, v in res["original"].items()}
+    assert set(got) == set(ref)
+    for k in ("mask", "mask_post", "lesion", "scan"):
+        assert got[k].shape == o_size and np.array_equal(got[k], ref[k]), k
+    assert np.abs(got["htp"] - ref["htp"]).max() <= 1e-6
+    assert res["mask"].shape == scan.shape                       # the working-resolution results stay what they were
+    assert res["iou"] == O.iou(ref["mask"] > 0, ref["lesion"] > 0, 1e-5)
+    assert res["iou_post"] == O.iou(ref["mask_post"] > 0, ref["lesion"] > 0, 1e-5)
+    assert res["dice"] == O.dice(ref["mask"] > 0, ref["lesion"] > 0, 1e-5)
+    assert res["dice_post"] == O.dice(ref["mask_post"] > 0, ref["lesion"] > 0, 1e-5)
+    with pytest.raises(ValueError):
+        LobeInference(model, resample_size=32).run(scan, lobe, spacing, lesion=lesion, original_size=o_size)

@@ -307,3 +307,25 @@ def test_inference_tail_helpers(golden_dir):
     ves = z["b"]
     _, post_v, _ = O.lesion_post_process(htp, scan, lobe, ves, 0.5)
     assert np.array_equal(post_v, post & (ves == 0))
+
+
+def test_resample_itk_restatement_properties():
+    """`O.resample_itk` (the sitk.ResampleImageFilter call of utils.resample, restated; SimpleITK absent: unpinned) against what
+    that call's published semantics imply, on cases small enough to spell out: the identity on an unchanged grid; nearest
+    neighbour at half-integer positions rounds UP; voxels beyond size_in - 0.5 take the default value 0; linear agrees with
+    the crop -> R^3 restatement (`resample_itk_linear`: the same call with spacing * in / out); int16 results are truncated."""
+    rng = np.random.default_rng(2)
+    a = rng.integers(-1000, 1000, size=(5, 6, 7)).astype(np.int16)
+    sp = (1.5, 0.7, 0.7)
+    for how in ("nearest", "linear"):
+        assert np.array_equal(O.resample_itk(a, sp, sp, a.shape, how), a)
+    # z spacing halved: c = 0, 0.5, 1, 1.5, ...: nearest takes floor(c + 0.5) = 0, 1, 1, 2, 2, ...; c = 4.5 (o = 9) is outside
+    up = O.resample_itk(a, sp, (0.75, 0.7, 0.7), (11, 6, 7), "nearest")
+    assert np.array_equal(up[:9], a[[0, 1, 1, 2, 2, 3, 3, 4, 4]]) and (up[9:] == 0).all()
+    lin = O.resample_itk(a, sp, (0.75, 0.7, 0.7), (11, 6, 7), "linear")
+    mid = (a[0].astype(np.float64) + a[1].astype(np.float64)) / 2.0
+    assert np.array_equal(lin[1], np.trunc(mid).astype(np.int16)) and np.array_equal(lin[8], a[4]) and (lin[9:] == 0).all()
+    f = rng.random((9, 12, 10)).astype(np.float32)
+    size = (16, 7, 10)
+    req = tuple(1.0 * n / m for n, m in zip(f.shape, size))
+    assert np.abs(O.resample_itk(f, (1.0, 1.0, 1.0), req, size, "linear") - O.resample_itk_linear(f, size)).max() <= 1e-6
