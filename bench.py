@@ -347,31 +347,31 @@ def main():
     # widest stage in slices: 251 of 288 GB at its peak); should that not fit on this device (other tenants, a
     # smaller part), fall back to gradient-accumulated micro-batches of half the size and say so in the output.
     micro = min(args.micro, args.chunks)
-    if micro > 16:
-        args.warmup = max(args.warmup, 1)      # (the first step doubles as the "does it fit" probe)
+    # The "does it fit" probe: forward + loss + backward of one micro-batch with NO collective and no optimiser step
+    # (DataParallelTrainer.probe), then ONE all-reduce of the outcome on every rank -- so that a rank that runs out of memory
+    # and its peers that do not still issue the same collectives -- and every rank halves together.
+    while micro > 16 or use_dist:
+        fits = True
+        try:
+            if os.environ.get("DRAM_BENCH_FAKE_OOM_RANK") == str(rank) and micro == min(args.micro, args.chunks):
+                raise torch.OutOfMemoryError("DRAM_BENCH_FAKE_OOM_RANK (test hook: this rank's first probe fails)")
+            trainer.probe(batch, micro)
+        except torch.OutOfMemoryError:
+            fits = False
+            torch.cuda.empty_cache()
+        if use_dist:
+            ft = torch.tensor([1 if fits else 0], device=dev)
+            dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+            fits = bool(int(ft.item()))
+        if fits:
+            break
+        if micro <= 8:
+            raise RuntimeError(f"bench.py: a micro-batch of {micro} chunks does not fit on every rank's device")
+        micro //= 2
+        if rank == 0:
+            print(f"bench.py: out of memory, retrying with micro-batch {micro}", file=sys.stderr, flush=True)
     for i in range(args.warmup):
-        while True:
-            try:
-                # The probe step reduces its gradients AFTER backward: an out-of-memory error in the middle of an overlapped
-                # backward would leave this rank with bucket all-reduces already issued that its retry issues again -- one
-                # collective more than its peers.  Without the overlap nothing is issued before the step is known to fit.
-                trainer.overlap = (not args.no_overlap) and i > 0
-                trainer.step(batch, micro)
-                trainer.overlap = not args.no_overlap
-                break
-            except torch.OutOfMemoryError:
-                if micro <= 8:
-                    raise
-                opt.zero_grad(set_to_none=True)
-                torch.cuda.empty_cache()
-                micro //= 2
-                if rank == 0:
-                    print(f"bench.py: out of memory, retrying with micro-batch {micro}", file=sys.stderr, flush=True)
-    trainer.overlap = not args.no_overlap
-    if use_dist:       # every rank must run the same micro-batch (same number of launches between barriers)
-        mt = torch.tensor([micro], device=dev)
-        dist.all_reduce(mt, op=dist.ReduceOp.MIN)
-        micro = int(mt.item())
+        trainer.step(batch, micro)
     args.micro = micro
     # per-kernel HIP events (one pair per conv launch, on the launch stream) ride along in the timed region
     use_timer = not args.no_kernel_timer

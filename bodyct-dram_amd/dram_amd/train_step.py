@@ -210,6 +210,22 @@ class DataParallelTrainer:
                 off += n
         self._begin()
 
+    def probe(self, batch, micro_batch=None):
+        """Forward, loss and backward of the first micro-batch WITHOUT any collective and without the optimiser step, the
+        gradients dropped again: "does this micro-batch size fit on this device" as a rank-local question.  A caller with
+        several ranks agrees on the answer afterwards (one all-reduce per attempt on every rank, whatever each rank found);
+        an out-of-memory error inside `step` instead would leave the ranks with different numbers of collectives issued."""
+        n = len(batch)
+        mb = n if not micro_batch else min(micro_batch, n)
+        self.opt.zero_grad(set_to_none=True)
+        try:
+            b = batch.micro(0, mb)
+            dense, refined = self.model(b.images, b.lobes)
+            reg, seg = self.loss_fn(dense, b, refined=None if refined is dense else refined)
+            (self.loss_factors[0] * reg + self.loss_factors[1] * seg).backward()
+        finally:
+            self.opt.zero_grad(set_to_none=True)
+
     def step(self, batch, micro_batch=None, global_batch=None):
         """Returns the (detached, device) loss components of this rank's batch: reg summed, seg weighted by
         the share of the global batch.  `global_batch`: number of chunks over all ranks (default: every rank

@@ -188,3 +188,20 @@ def test_bench_two_ranks_over_gloo_as_a_child_process():
     assert line["cpu_baseline"] is None and "N = 1" in line["cpu_baseline_note"]
     ar = line["allreduce"]
     assert ar["overlapped_with_backward"] and ar["buckets_started_inside_backward"] == ar["buckets"] >= 1, ar
+
+
+def test_bench_ranks_agree_on_the_micro_batch_when_one_runs_out_of_memory():
+    """One rank's "does it fit" probe fails (test hook DRAM_BENCH_FAKE_OOM_RANK), the other's does not: both must halve the
+    micro-batch together and finish -- the probe issues no collective of its own, the outcome is agreed by one all-reduce per
+    attempt (an out-of-memory error inside a real step would leave the ranks with different numbers of collectives issued)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DRAM_BENCH_FAKE_OOM_RANK="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--chunks", "32",
+                        "--size", "16", "--micro", "32", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-att"],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "retrying with micro-batch 16" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["micro_batch"] == 16 and line["dist"]["ranks_seen"] == 2 and line["loss"]["finite"]
