@@ -1084,13 +1084,21 @@ template <int BX>
 __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items) {
     using G = FwdWzyGeomT<BX>;
     constexpr int XI = G::XI_STRIDE, KHS = G::KH_STRIDE, IN_STAGE = G::IN_STAGE, KXS = G::KXS;
-    constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE, WPASS = G::WPASS;
+    constexpr int WTS = G::WT_STRIDE, STAGE = G::STAGE;
+    static_assert(WTS == 4 * 64 && G::W_STAGE == 48 * WTS, "a filter matrix of a chunk = 1 KB = one LDS-DMA instruction of a wave");
     constexpr int SL0 = 7;         // first of the four iterations that carry the staging slices (8 measured the same)
     // Iterations in which the next chunk's loads are issued: the input patch right behind the barrier (it is wanted first, at
-    // SL0), the filter tile three iterations later (wanted at the chunk's end; never in iteration 0, where an item's epilogue
-    // uses the idle stage as its exchange buffer).  Measured (plain / fused launches, against patch 1 + filters 2): patch 0 +
-    // filters 2: -5 % / -1 %; patch 0 + filters 3 or 4: -6.4 % / -2...0 %; patch 0 + filters 1: +0 % / +2 %.
-    constexpr int LD_IN = 0, LD_W = 2;
+    // SL0), the filter tile from iteration 1 (wanted at the chunk's end; never in iteration 0, where an item's epilogue uses the
+    // idle stage as its exchange buffer).  WHO issues them: the raw rows waves 4-7 (four LDS-DMA instructions, iterations 0-1),
+    // the filter tile waves 0-3 (twelve, iterations 1-6) -- a memory instruction stalls the wave that issues it for hundreds of
+    // cycles (scattered rows more than contiguous tiles), during which only its SIMD partner feeds the matrix pipe, and a
+    // chunk ends when the slower wave group reaches the barrier.  Measured (stamps, cycles per chunk): with the filter tile
+    // spread over all eight waves (six each, iterations 2-4) waves 0-3 waited 3,900 cycles per chunk at the barrier for waves
+    // 4-7; with this split 160 against 900.  A/B of whole builds in one gpurun call: -1.0...-1.9 % ([4,64->64] / [4,192->64],
+    // plain and + statistics), lazy -0.7 %; ten pieces + two on waves 4-7: the same; eight + four: +0.5 %; raw pieces moved to
+    // waves 0-3 (one / two of the four): +1...+2 % / +3...+4 %; the tile one iteration later: no gain.
+    constexpr int LD_IN = 0, LD_W = 1;
+    constexpr int FPIECES = 12;    // filter pieces (one 1 KB matrix each) per filter-loading wave and chunk: iterations LD_W .. LD_W + 5
     static_assert(8 * 32 * 64 <= STAGE, "the epilogue exchange fits one (idle) stage");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1149,10 +1157,10 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
     unsigned dv1[4], dv2[4];       // byte offset of the lane's piece inside a channel of source 1 / 2 (OOB: outside the volume)
     const float* dg_base1 = nullptr;   // sample n of source 1 / 2
     const float* dg_base2 = nullptr;
-    unsigned wvoff = 0;            // filter slot 0 of the item's channel tile; slot p is 8 filter matrices further
+    unsigned wvoff = 0;            // (waves 0-3) filter matrix `wave` of the item's channel tile, chunk 0; piece p is 4 matrices further
     const int nchunk = (Cin + 3) >> 2;
     const unsigned wchunk_bytes = 16u * (unsigned)a.Cout;
-    const unsigned wpass_bytes = 8u * (unsigned)nchunk * wchunk_bytes;
+    const unsigned wpass_bytes = 4u * (unsigned)nchunk * wchunk_bytes;     // four filter matrices further
     const __amdgpu_buffer_rsrc_t wsrd = make_rsrc(a.wt, 48u * 16u * (unsigned)nchunk * (unsigned)a.Cout);
     const int C1 = a.src.C1;
 
@@ -1197,7 +1205,7 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
                     rowmask[r] = ok ? 0xffffffffu : 0u;
                 }
             }
-            const int t = tid >> 6, r = tid & 63;
+            const int t = (tid >> 6) & 3, r = tid & 63;      // (the filter DMA is issued by waves 0-3: matrices t, t + 4, ...)
             wvoff = 4u * (unsigned)(((t * nchunk) * 2 + (r >> 5)) * k->Cout * 2 + co0 * 2 + 4 * (r & 31));
         };
         auto set_fetch_item = [&](int item) {
@@ -1300,9 +1308,10 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
             lc_lo = (lc_has && (rb & (first ? 1u : 2u))) ? 0.f : -INFINITY;
         };
         // the staged chunk's filter tile, in two halves: global -> LDS directly
-        auto load_filters = [&](int c0, float* nstage, int p) {       // piece p of WPASS
+        auto load_filters = [&](int c0, float* nstage, int p) {       // piece p of FPIECES: filter matrix wave + 4 p (waves 0-3)
+            if (EXTRA) return;
             const unsigned cb = (unsigned)(c0 >> 2) * wchunk_bytes;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + 4 * (p * 512 + 64 * wave)), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)(nstage + IN_STAGE + WTS * (wave + 4 * p)), 16,
                                                      (int)wvoff, (int)(cb + (unsigned)p * wpass_bytes), 0, 0);
         };
         // normalise + ReLU of the raw patch; the zero padding belongs to the ACTIVATED tensor (a plain source / the channel
@@ -1508,7 +1517,7 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
         }
         if (lazy) load_coef(0);
     #pragma unroll
-        for (int p = 0; p < WPASS; ++p) load_filters(0, lds, p);
+        for (int p = 0; p < FPIECES; ++p) load_filters(0, lds, p);
         __syncthreads();                            // (waits for the wave's own loads first: the raw rows of all waves are in)
         read_raw(raw0);
         if (lazy) { activate(0); activate(1); }
@@ -1534,7 +1543,7 @@ __device__ __forceinline__ void fwd_wzy_body(const ConvArgs& a, int total_items)
     #endif
             if (it == LD_IN && half == 1 && has_next && lazy) load_coef(s_c0);
     #ifndef DRAM_WZY_DIAG_NOFILT
-            if (it >= LD_W && it < LD_W + WPASS / 2 && has_next) load_filters(s_c0, nstage, 2 * (it - LD_W) + half);
+            if (it >= LD_W && it < LD_W + FPIECES / 2 && has_next) load_filters(s_c0, nstage, 2 * (it - LD_W) + half);
     #endif
     #ifndef DRAM_WZY_DIAG_NOSTAGE
             if (it == SL0 - 1 && half == 1) read_raw(raw0 + (cur_ ^ 1) * G::RAW_STAGE);
