@@ -26,7 +26,7 @@ for (N, Ci, Co, S) in [(4, 64, 64, 128), (4, 192, 64, 128), (16, 256, 256, 32)]:
             torch.cuda.synchronize()
         out = (ctypes.c_ulonglong * 8)()
         lib.dram_debug_wgrad_stamps(out, 0)
-        for half, who in ((0, "waves 0-3 (transform)"), (1, "waves 4-7 (fetch)")):
+        for half, who in ((0, "waves 0-3 (fetch + transform + one co tile)"), (1, "waves 4-7 (three co tiles)")):
             o = out[4 * half:4 * half + 4]
             nbox = max(o[3], 1)
             print(f"[{N},{Ci}->{Co},{S}^3] {tag:5s} {who}: cycles per wave and box: MFMAs + rides {o[0] / nbox:.0f}, fetch wait {o[1] / nbox:.0f}, "
