@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--size", type=int, default=80)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-fused", action="store_true", help="the per-op path instead of the fused engine")
+    ap.add_argument("--dc3d", action="store_true", help="DC3D(st_dram_ref) instead of the attention model (same shape: the reference's own training batch)")
     a = ap.parse_args()
     import models
     from dram_amd.train_step import DataParallelTrainer, synthetic_batch
@@ -29,7 +30,11 @@ def main():
                at_k_size=3, at_merge_type="scaled_dot_product_relu", at_self_loop=False, at_layers=[-1, 0, 1],
                at_p_enc_dim=0, at_geo_f_dim=0)
     torch.manual_seed(0)
-    m = models.DC3DATGeneric(**cfg)
+    if a.dc3d:
+        from dram_amd.configs import ST_DRAM_REF_MODEL
+        m = models.DC3D(**ST_DRAM_REF_MODEL)
+    else:
+        m = models.DC3DATGeneric(**cfg)
     m.init(models.HeNorm(mode="fan_in"))
     m = m.cuda().train()
     m.fused = not a.no_fused
@@ -42,6 +47,10 @@ def main():
         reg, seg = tr.step(batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    if a.dc3d:
+        print({"model": "DC3D(st_dram_ref)", "fused_engine": bool(m.fused), "peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "chunks": a.n,
+               "size": a.size, "ms_per_step": dt * 1e3, "voxels_per_s": a.n * a.size ** 3 / dt, "reg": float(reg), "seg": float(seg)})
+        return
     # the attention alone
     att = m.attention_module
     cam = torch.randn(a.n, 1, 64, 64, 64, device="cuda", requires_grad=True)
